@@ -1,0 +1,237 @@
+/* vtx.h -- C ABI of libvtx.so, the MI355X (gfx950) video-transformer hot path.
+ *
+ * The reference (mx-mark/VideoTransformer-pytorch) has no FFI layer: its hot
+ * path is ATen calls made from transformer.py / video_transformer.py.  This
+ * header is the boundary a maintainer binds instead of those ATen calls; every
+ * entry point names the reference lines it replaces.  Python binds it with
+ * ctypes (videotransformer-pytorch_amd/vtx/_lib.py); see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every device pointer is BORROWED for the call; the library never
+ *     allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).
+ *   - returns VTX_OK (0) or a negative VTX_E* code; never throws.
+ *     vtx_last_error_string() gives the reason for the last failure on the
+ *     calling thread.
+ *   - dtype VTX_F32 = exact-fp32 path (f32 MFMA / fp32 VALU), VTX_BF16 = bf16
+ *     storage with fp32 accumulation (bf16 MFMA).  Parameters that stay fp32 in
+ *     both modes (bias, LayerNorm gamma/beta, all gradients of parameters) are
+ *     typed float* here.
+ *   - "row map": a logical row m of an operand lives at physical row
+ *         base + m + (m / grp) * skip
+ *     which expresses "skip the cls row of every clip" (grp = P*T, skip = 1,
+ *     base = 1) and "one row per clip" (grp = 1, skip = P*T) without copies.
+ *     grp <= 0 means identity (+ base).
+ */
+#ifndef VTX_H_
+#define VTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTX_OK 0
+#define VTX_EINVAL (-1)   /* bad shape / null pointer / unsupported combination */
+#define VTX_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned  */
+#define VTX_ELAUNCH (-3)  /* hipGetLastError() after launch != hipSuccess      */
+#define VTX_EWS (-4)      /* workspace too small                               */
+
+#define VTX_F32 0
+#define VTX_BF16 1
+
+typedef struct {
+  int grp;   /* rows per group (<=0: no groups) */
+  int skip;  /* extra physical rows at the start of every group */
+  int base;  /* physical row of logical row 0 */
+} vtx_rowmap;
+
+int vtx_version(void);
+const char* vtx_last_error_string(void);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * Replaces nn.LayerNorm in the blocks (transformer.py:215,257 / :321,359 /
+ * :418,439 / :495,519; eps 1e-5) and the final norm (video_transformer.py:119,
+ * 251 / :401,527; eps 1e-6).  fp32 statistics; saves mean / rstd per row. */
+int vtx_layernorm_fwd(int dtype, int rows, int D, const void* x, long ldx, vtx_rowmap xmap,
+                      const float* gamma, const float* beta, float eps,
+                      void* y, long ldy, vtx_rowmap ymap, float* mean, float* rstd, void* stream);
+/* dx[xmap(m)] = (dres ? dres[xmap(m)] : 0) + LN'(dy[m]);  dgamma/dbeta += column sums.
+ * workspace: vtx_layernorm_bwd_workspace(rows, D) bytes. */
+size_t vtx_layernorm_bwd_workspace(int rows, int D);
+int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, vtx_rowmap dymap,
+                      const void* x, long ldx, vtx_rowmap xmap, const float* mean, const float* rstd,
+                      const float* gamma, const void* dres, void* dx, long lddx,
+                      float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+
+/* ----------------------------------------------------------------------- GEMM
+ * C[M,N] = epilogue(A[M,K] * B[N,K]^T).  Replaces every nn.Linear forward and
+ * input-gradient on the path: qkv / proj (transformer.py:160-175), temporal_fc
+ * (:225,267), FFN (:498-507,520-521), the patch/tubelet projection after the
+ * patch gather (:116-126,142,146), MaskFeat decoder_pred
+ * (video_transformer.py:855,878).
+ * Epilogue order:  v = acc (+bias[n]);  act GELU(erf): C2 = v, v = gelu(v);
+ *                  v *= gelu'(dgelu_in[m][n]);  v *= row_scale[idx(m)];
+ *                  v += R[rmap(m) or m % r_period][n];  C[cmap(m)][n] = v.
+ * Rows m >= split_row (if split_row > 0) are stored to Csplit[m - split_row]
+ * with bias/act/scale applied but no residual (the per-frame cls rows of the
+ * divided spatial attention, transformer.py:371-373). */
+typedef struct {
+  int dtype;
+  int M, N, K;
+  const void* A; long lda; vtx_rowmap amap;
+  const void* B; long ldb;            /* [N,K], K contiguous */
+  void* C; long ldc; vtx_rowmap cmap;
+  const float* bias;                  /* [N] or NULL */
+  int act;                            /* 0 none, 1 GELU(erf) */
+  void* C2; long ldc2;                /* pre-activation copy when act == 1 (may be NULL) */
+  const void* dgelu_in; long ld_dgelu;/* multiply by gelu'(x) (FFN backward), or NULL */
+  const float* row_scale;             /* DropPath keep-scale per row group, or NULL */
+  int rs_d1, rs_m1, rs_d2, rs_m2;     /* idx(m) = (m / rs_d1) * rs_m1 + (m % rs_d2) * rs_m2 */
+  const void* R; long ldr; vtx_rowmap rmap; int r_period; /* residual; r_period>0: row m % r_period */
+  int split_row; void* Csplit; long ldsplit;
+} vtx_gemm_desc;
+int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream);
+
+/* Weight gradient: C[N1,N2] (fp32) (+)= sum_m A[amap(m)][n1] * B[bmap(m)][n2].
+ * Replaces autograd's mm(grad^T, input) for every Linear above.  Split over M
+ * into `splits` slabs reduced by a second kernel (deterministic). */
+typedef struct {
+  int dtype;
+  int M, N1, N2;
+  const void* A; long lda; vtx_rowmap amap;
+  const void* B; long ldb; vtx_rowmap bmap;
+  float* C; long ldc; int accumulate;
+  void* workspace; size_t ws_bytes;
+} vtx_gemm_tn_desc;
+size_t vtx_gemm_tn_workspace(int M, int N1, int N2);
+int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream);
+
+/* out[n] (+)= sum_m A[amap(m)][n]   (bias gradients). */
+size_t vtx_colsum_workspace(int M, int N);
+int vtx_colsum(int dtype, int M, int N, const void* A, long lda, vtx_rowmap amap,
+               float* out, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ Attention
+ * softmax(q k^T * scale) v per (sequence, head).  Replaces transformer.py:
+ * 167-174 and the rearranges around it (:250, :352-356, :375).  qkv feature
+ * order [3][head][hd] (:167).
+ * mode VTX_ATTN_CONTIG: sequence s = rows [s*L, (s+1)*L) of qkv / out.
+ * mode VTX_ATTN_SPACE : divided spatial attention.  qkv is in natural token
+ *   order [B, 1+P*T, 3D]; sequence s=(b,t) has L = 1+P tokens: i=0 is the cls
+ *   row of clip b, i>=1 is token 1+(i-1)*T+t.  out is [B*P*T + B*T, D]: token
+ *   rows first (clip-major, (p t) order, no cls), then one cls row per (b,t).
+ * lse: [S,H,L] fp32 log-sum-exp (saved for backward).  probs (optional,
+ *   fp32 [S,H,L,L]) materialises the softmax for get_last_selfattention
+ *   (video_transformer.py:258-261). */
+#define VTX_ATTN_CONTIG 0
+#define VTX_ATTN_SPACE 1
+typedef struct {
+  int dtype, mode;
+  int S, L, H, hd;
+  int B, T, P;                  /* VTX_ATTN_SPACE only */
+  const void* qkv; long ld_qkv;
+  void* out; long ld_out;
+  float* lse;
+  float* probs;
+  float scale;
+} vtx_attn_desc;
+int vtx_attn_fwd(const vtx_attn_desc* d, void* stream);
+
+/* dqkv from (qkv, out, dout, lse).  dout/out share the forward `out` layout.
+ * VTX_ATTN_SPACE: token rows of dqkv in natural order; the T per-frame
+ * gradients of each clip's cls row go to dqkv_cls [B*T, 3D] (same dtype) and
+ * are summed over t by vtx_cls_qkv_reduce.  delta: [S,H,L] fp32 scratch. */
+typedef struct {
+  vtx_attn_desc f;
+  const void* dout; long ld_dout;
+  void* dqkv; long ld_dqkv;
+  void* dqkv_cls;
+  float* delta;
+} vtx_attn_bwd_desc;
+int vtx_attn_bwd(const vtx_attn_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------- divided-attention glue ops */
+/* out[b,0,:] = x[b,0,:] + mean_t a_cls[b*T+t,:]   (transformer.py:371-377) */
+int vtx_cls_mean_fwd(int dtype, int B, int T, int D, const void* a_cls, long lda,
+                     const void* x, void* out, long ld_tok, long rows_per_clip, void* stream);
+/* da[0:B*N]   = dout[b,1+n] * s[b*T + n%T];  da[B*N + b*T+t] = dout[b,0] * s[b*T+t] / T
+ * (backward of transformer.py:367-377; s may be NULL = 1) */
+int vtx_space_grad_prep(int dtype, int B, int T, int P, int D, const void* dout, long ld,
+                        const float* s, void* da, long ldda, void* stream);
+/* dqkv[b,0,:] = sum_t dqkv_cls[b*T+t,:]  (cls row replicated per frame, transformer.py:354-356) */
+int vtx_cls_qkv_reduce(int dtype, int B, int T, int W, const void* dqkv_cls, long ldc,
+                       void* dqkv, long ld, long rows_per_clip, void* stream);
+/* dst[dmap(m)] = src[smap(m)] * (s ? s[(m/rs_d1)*rs_m1 + (m%rs_d2)*rs_m2] : 1) */
+int vtx_row_scale_copy(int dtype, int rows, int D, const void* src, long lds, vtx_rowmap smap,
+                       void* dst, long ldd, vtx_rowmap dmap, const float* s,
+                       int rs_d1, int rs_m1, int rs_d2, int rs_m2, void* stream);
+/* out[j,:] (+)= scale * sum_{i<ni} in[base + i*si + j*sj, :]   (fp32 out).  in_dtype: VTX_F32/BF16. */
+int vtx_reduce_rows(int in_dtype, int nj, int ni, int D, const void* in, long ld, long base,
+                    long si, long sj, float* out, long ldo, float scale, int accumulate, void* stream);
+/* Weight staging: W fp32 [R,C] -> Wc (dtype, [R,C], optional) and WcT (dtype, [C,R], optional). */
+int vtx_cast_transpose(int dtype, int R, int C, const float* W, void* Wc, void* WcT, void* stream);
+/* dst (dtype) = src (fp32), n elements; and the reverse. */
+int vtx_cast_from_f32(int dtype, size_t n, const float* src, void* dst, void* stream);
+int vtx_cast_to_f32(int dtype, size_t n, const void* src, float* dst, void* stream);
+
+/* ------------------------------------------------------ patch / tubelet embed
+ * Gather of PatchEmbed.forward (transformer.py:138-151): clip [B,T,C,H,W]
+ * (fp32) -> rows[(b, p, t'), K] in `dtype`, already in token order (p major,
+ * t' minor), K index = c*ts*ps*ps + kt*ps*ps + kh*ps + kw (ts = 1 for Conv2d).
+ * frame_major != 0 keeps the reference's (b t') p row order instead (ViViT
+ * fact_encoder, space_only). */
+int vtx_patch_rows(int dtype, int B, int T, int C, int H, int W, int ps, int ts,
+                   const float* clip, void* rows, long ldr, int frame_major, void* stream);
+/* E[p*T+t,:] = bias + pos[1+p,:] + (time ? time[t,:] : 0);  cls_row = cls + pos[0]
+ * (prepare_tokens, video_transformer.py:199-237).  E, cls_row in `dtype`. */
+int vtx_embed_table(int dtype, int P, int T, int D, const float* bias, const float* pos,
+                    const float* time_embed, const float* cls, void* E, void* cls_row,
+                    int frame_major, void* stream);
+
+/* ------------------------------------------------------------------------ HOG
+ * extract_hog_features (dataset.py:39-45) for F frames [F,H,W,3] uint8 ->
+ * [F, H/16, W/16, 108] float64, bit-exact vs skimage 0.18.3 when `table` is
+ * the |g_row| x |g_col| magnitude table built by vtx_hog_build_table (host
+ * libm hypot, 256*256 doubles uploaded by the caller).  bins (optional):
+ * [F,3,H,W] int32 orientation-bin ids. */
+size_t vtx_hog_table_bytes(void);
+int vtx_hog_build_table(double* host_table);
+int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table,
+                double* out, int32_t* bins, void* stream);
+
+/* ------------------------------------------------------------ MaskFeat head
+ * Mask-token blend (video_transformer.py:914-919): x [B, Tq*Hq*Wq, C], mask
+ * [B,Tq,g,g] uint8 upsampled by r = Hq/g (nearest). */
+int vtx_maskfeat_blend_fwd(int dtype, int B, int Tq, int Hq, int Wq, int C, int g,
+                           const void* x, const uint8_t* mask, const float* mask_token,
+                           void* out, void* stream);
+/* dx = dy * (1-w);  dtoken[C] (+)= sum dy * w  (fp32). */
+int vtx_maskfeat_blend_bwd(int dtype, int B, int Tq, int Hq, int Wq, int C, int g,
+                           const void* dy, const uint8_t* mask, void* dx, float* dtoken,
+                           void* stream);
+/* Masked MSE (video_transformer.py:882-901).  pred: decoder output without the
+ * cls row, [B, Tq*g*g, ts*Cf] in `dtype` (Cf = 108 HOG features, ts = temporal
+ * stride); target f64 [B, Tq*ts, g, g, Cf]; cmask uint8 [B, Tq*ts, g, g] = mask
+ * repeated over ts with non-centre frames zeroed (host-built, :889-896).
+ * loss_out[0] = loss (f64), loss_out[1] = sum(cmask).  scratch: f64[2] zeroed
+ * by the call. */
+int vtx_maskfeat_loss_fwd(int dtype, int B, int Tq, int ts, int g, int Cf, const void* pred, long ldp,
+                          const double* target, const uint8_t* cmask, double* loss_out, void* stream);
+/* dpred = gloss * 2 (pred - target) * cmask / (Cf * (sum(cmask) + 1e-5)) */
+int vtx_maskfeat_loss_bwd(int dtype, int B, int Tq, int ts, int g, int Cf, const void* pred, long ldp,
+                          const double* target, const uint8_t* cmask, const double* loss_out,
+                          float gloss, void* dpred, long lddp, void* stream);
+
+/* MFMA / LDS-transpose layout self-test: runs one-hot probes through the
+ * instructions the GEMM kernels rely on and writes a report; returns the
+ * number of layout assumptions that failed (0 = all hold). */
+int vtx_selftest(char* report, size_t report_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTX_H_ */

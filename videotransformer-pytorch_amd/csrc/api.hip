@@ -1,0 +1,147 @@
+// api.hip -- error plumbing, version, and the instruction-layout self-test.
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace vtx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return VTX_ELAUNCH;
+  }
+  return VTX_OK;
+}
+
+// ---- probes (one wave each) ---------------------------------------------------------
+// D = A(32x16) * B(16x32) with the operand layout the GEMM kernels assume:
+// lane l holds A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31], j = 0..7; D in the documented C layout.
+__global__ void probe_mfma_bf16(const float* A, const float* B, float* D) {
+  const int l = threadIdx.x;
+  union { bf16x8 v; bf16raw s[8]; } a, b;
+  for (int j = 0; j < 8; ++j) {
+    a.s[j] = f2bf(A[(l & 31) * 16 + 8 * (l >> 5) + j]);
+    b.s[j] = f2bf(B[(8 * (l >> 5) + j) * 32 + (l & 31)]);
+  }
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+}
+// D = A(32x2) * B(2x32): lane l holds A[l&31][l>>5], B[l>>5][l&31].
+__global__ void probe_mfma_f32(const float* A, const float* B, float* D) {
+  const int l = threadIdx.x;
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(l & 31) * 2 + (l >> 5)], B[(l >> 5) * 32 + (l & 31)], acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+}
+// ds_read_b64_tr_b16 with the address pattern of gemm_tn: LDS holds lds[e] = e.
+__global__ void probe_tr(unsigned short* out) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[16 * 160];
+  const int l = threadIdx.x;
+  for (int e = l; e < 16 * 160; e += 64) lds[e] = (unsigned short)e;
+  __syncthreads();
+  const int row = 8 * (l >> 5) + ((l & 15) >> 2), col = 16 * ((l >> 4) & 1) + 4 * (l & 3);
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + row * 160 + col));
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
+}
+
+}  // namespace vtx
+
+using namespace vtx;
+
+extern "C" int vtx_version(void) { return 100; }  // 0.1.0
+extern "C" const char* vtx_last_error_string(void) { return g_err; }
+
+extern "C" int vtx_selftest(char* report, size_t report_bytes) {
+  std::string rep;
+  int fails = 0;
+  auto say = [&](const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    rep += buf;
+  };
+  float *dA = nullptr, *dB = nullptr, *dD = nullptr;
+  unsigned short* dT = nullptr;
+  if (hipMalloc(&dA, 32 * 16 * 4) != hipSuccess || hipMalloc(&dB, 16 * 32 * 4) != hipSuccess ||
+      hipMalloc(&dD, 32 * 32 * 4) != hipSuccess || hipMalloc(&dT, 256 * 2) != hipSuccess) {
+    set_error("selftest: hipMalloc failed");
+    return VTX_ELAUNCH;
+  }
+  std::vector<float> A(32 * 16), B(16 * 32), D(32 * 32);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((int)((s >> 24) % 15) - 7); };
+  // ---- bf16 32x32x16
+  for (auto& v : A) v = rnd();
+  for (auto& v : B) v = rnd();
+  hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(probe_mfma_bf16, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+  hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      float r = 0.f;
+      for (int k = 0; k < 16; ++k) r += A[i * 16 + k] * B[k * 32 + j];
+      if (r != D[i * 32 + j]) ++bad;
+    }
+  say("mfma_f32_32x32x16_bf16 layout: %s (%d/1024 mismatches)\n", bad ? "FAIL" : "ok", bad);
+  fails += bad != 0;
+  // ---- f32 32x32x2
+  std::vector<float> A2(32 * 2), B2(2 * 32);
+  for (auto& v : A2) v = rnd();
+  for (auto& v : B2) v = rnd();
+  hipMemcpy(dA, A2.data(), A2.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dB, B2.data(), B2.size() * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(probe_mfma_f32, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+  hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+  bad = 0;
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      const float r = A2[i * 2] * B2[j] + A2[i * 2 + 1] * B2[32 + j];
+      if (r != D[i * 32 + j]) ++bad;
+    }
+  say("mfma_f32_32x32x2_f32 layout: %s (%d/1024 mismatches)\n", bad ? "FAIL" : "ok", bad);
+  fails += bad != 0;
+  // ---- ds_read_b64_tr_b16
+  std::vector<unsigned short> T(256);
+  hipLaunchKernelGGL(probe_tr, dim3(1), dim3(64), 0, 0, dT);
+  hipMemcpy(T.data(), dT, 512, hipMemcpyDeviceToHost);
+  bad = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int j = 0; j < 4; ++j) {
+      const int want = (8 * (l >> 5) + j) * 160 + (l & 31);
+      if (T[l * 4 + j] != want) ++bad;
+    }
+  say("ds_read_b64_tr_b16 gather: %s (%d/256 mismatches)\n", bad ? "FAIL" : "ok", bad);
+  if (bad) {
+    say("  observed (lane: row,col x4):\n");
+    for (int l = 0; l < 64; ++l) {
+      say("  %2d:", l);
+      for (int j = 0; j < 4; ++j) say(" %d,%d", T[l * 4 + j] / 160, T[l * 4 + j] % 160);
+      say("\n");
+    }
+  }
+  fails += bad != 0;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { say("device error: %s\n", hipGetErrorString(e)); ++fails; }
+  hipFree(dA); hipFree(dB); hipFree(dD); hipFree(dT);
+  if (report && report_bytes) {
+    strncpy(report, rep.c_str(), report_bytes - 1);
+    report[report_bytes - 1] = 0;
+  }
+  return fails;
+}

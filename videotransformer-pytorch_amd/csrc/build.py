@@ -1,0 +1,62 @@
+"""Build libvtx.so (gfx950) with hipcc -- no torch headers, no cmake.
+
+    python videotransformer-pytorch_amd/csrc/build.py [--force]
+
+Each .hip file is compiled to an object (skipped when up to date) and linked into
+videotransformer-pytorch_amd/libvtx.so.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, 'libvtx.so')
+OBJ = os.path.join(HERE, '_obj')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+SOURCES = ['api.hip', 'ln.hip', 'gemm_nt.hip', 'gemm_tn.hip', 'attn.hip', 'elementwise.hip', 'hog.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result', '-Wno-unused-value']
+EXTRA = {'hog.hip': ['-ffp-contract=off']}       # bit-exact HOG: no fma contraction
+
+
+def _deps():
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
+    hdrs.append(os.path.join(PKG, '..', 'include', 'vtx.h'))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+    spath = os.path.join(HERE, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) > max(os.path.getmtime(spath), _deps())):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ['-c', spath, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(OUT):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        if verbose:
+            print(f'built {OUT}')
+    elif verbose:
+        print(f'{OUT} up to date')
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

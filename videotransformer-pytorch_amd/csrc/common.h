@@ -1,0 +1,109 @@
+// common.h -- shared device/host helpers for libvtx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vtx.h"
+
+namespace vtx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned short bf16raw;  // storage type of a bf16 element
+
+// ---- bf16 <-> fp32 (round-to-nearest-even, NaN preserved) ------------------
+__host__ __device__ inline float bf2f(bf16raw v) {
+  union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
+}
+__host__ __device__ inline bf16raw f2bf(float f) {
+  union { uint32_t u; float f; } c; c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16raw)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16raw)(u >> 16);
+}
+
+// Element-type traits: T is `float` (VTX_F32) or `bf16raw` (VTX_BF16).
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int VEC = 4;               // elements per 16-byte vector
+  __device__ static inline float ld(const float* p) { return *p; }
+  __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct ET<bf16raw> {
+  static constexpr int VEC = 8;
+  __device__ static inline float ld(const bf16raw* p) { return bf2f(*p); }
+  __device__ static inline void st(bf16raw* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (bf16: one 16-B access; f32: two).
+__device__ inline void load8(const float* p, float (&v)[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ inline void load8(const bf16raw* p, float (&v)[8]) {
+  uint4 r = *reinterpret_cast<const uint4*>(p);
+  uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ inline void store8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ inline void store8(bf16raw* p, const float (&v)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- row maps ---------------------------------------------------------------
+__host__ __device__ inline long map_row(const vtx_rowmap& m, long r) {
+  long q = (m.grp > 0) ? (r / m.grp) * (long)m.skip : 0;
+  return (long)m.base + r + q;
+}
+inline vtx_rowmap ident_map() { vtx_rowmap m; m.grp = 0; m.skip = 0; m.base = 0; return m; }
+
+// ---- wave reductions (wave = 64) ---------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ inline float gelu_erf_grad(float x) {
+  // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- host-side error plumbing --------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define VTX_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::vtx::set_error(__VA_ARGS__);        \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace vtx

@@ -1,0 +1,355 @@
+// elementwise.hip -- HBM-bound glue kernels of the divided space-time block:
+// weight staging (cast + transpose), cls-token mean / replication gradients,
+// DropPath row scaling, strided row reductions (embedding gradients), the patch
+// gather of PatchEmbed and the positional/time embedding table.
+// All of them move each byte once with 16-byte vector accesses.
+#include "common.h"
+
+namespace vtx {
+
+// ---- W fp32 [R,C] -> Wc (T) [R,C] and WcT (T) [C,R] via a 64x64 LDS tile -------
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(int R, int C, const float* __restrict__ W,
+                                                             T* __restrict__ Wc, T* __restrict__ WcT) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      v = W[(long)r * C + c];
+      if (Wc) ET<T>::st(Wc + (long)r * C + c, v);
+    }
+    tile[rr][tx] = v;
+  }
+  if (!WcT) return;
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, r = r0 + tx;
+    if (r < R && c < C) ET<T>::st(WcT + (long)c * R + r, tile[tx][cc]);
+  }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(size_t n, const float* __restrict__ src, T* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    ET<T>::st(dst + i, src[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(size_t n, const T* __restrict__ src, float* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = ET<T>::ld(src + i);
+}
+
+// ---- out[b,0,:] = x[b,0,:] + mean_t a_cls[b*T+t,:] ------------------------------
+template <typename T>
+__global__ void cls_mean_fwd_kernel(int B, int T_, int D, const T* __restrict__ a_cls, long lda, const T* __restrict__ x,
+                                    T* __restrict__ out, long ld, long rows_per_clip) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per 8 columns
+  const int per = D / 8;
+  if (idx >= B * per) return;
+  const int b = idx / per, c = (idx - b * per) * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < T_; ++t) {
+    float v[8];
+    load8(a_cls + (long)(b * T_ + t) * lda + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+  }
+  float xv[8];
+  load8(x + (long)b * rows_per_clip * ld + c, xv);
+  const float inv = 1.0f / (float)T_;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = xv[j] + acc[j] * inv;
+  store8(out + (long)b * rows_per_clip * ld + c, acc);
+}
+
+// ---- da rows for the spatial projection backward ----------------------------------
+template <typename T>
+__global__ void space_grad_prep_kernel(int B, int T_, int P, int D, const T* __restrict__ dout, long ld,
+                                       const float* __restrict__ s, T* __restrict__ da, long ldda) {
+  const long per = D / 8;
+  const long N = (long)P * T_;
+  const long total = ((long)B * N + (long)B * T_) * per;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / per;
+    const int c = (int)(idx - row * per) * 8;
+    float v[8];
+    float sc;
+    if (row < (long)B * N) {
+      const long b = row / N, n = row - b * N;
+      load8(dout + (b * (N + 1) + 1 + n) * ld + c, v);
+      sc = s ? s[b * T_ + (n % T_)] : 1.0f;
+    } else {
+      const long bt = row - (long)B * N;
+      const long b = bt / T_;
+      load8(dout + (b * (N + 1)) * ld + c, v);
+      sc = (s ? s[bt] : 1.0f) / (float)T_;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= sc;
+    store8(da + row * ldda + c, v);
+  }
+}
+
+// ---- dqkv[b,0,:] = sum_t dqkv_cls[b*T+t,:] ----------------------------------------
+template <typename T>
+__global__ void cls_qkv_reduce_kernel(int B, int T_, int W, const T* __restrict__ src, long lds_, T* __restrict__ dst,
+                                      long ld, long rows_per_clip) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = W / 8;
+  if (idx >= B * per) return;
+  const int b = idx / per, c = (idx - b * per) * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < T_; ++t) {
+    float v[8];
+    load8(src + (long)(b * T_ + t) * lds_ + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+  }
+  store8(dst + (long)b * rows_per_clip * ld + c, acc);
+}
+
+// ---- dst[dmap(m)] = src[smap(m)] * s[idx(m)] ----------------------------------------
+template <typename T>
+__global__ void row_scale_copy_kernel(int rows, int D, const T* __restrict__ src, long lds_, vtx_rowmap smap,
+                                      T* __restrict__ dst, long ldd, vtx_rowmap dmap, const float* __restrict__ s,
+                                      int d1, int m1, int d2, int m2) {
+  const long per = D / 8;
+  const long total = (long)rows * per;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / per;
+    const int c = (int)(idx - m * per) * 8;
+    float v[8];
+    load8(src + map_row(smap, m) * lds_ + c, v);
+    if (s) {
+      const float sc = s[(m / d1) * m1 + (m % d2) * m2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= sc;
+    }
+    store8(dst + map_row(dmap, m) * ldd + c, v);
+  }
+}
+
+// ---- out[j,:] (+)= scale * sum_i in[base + i*si + j*sj, :] -----------------------------
+// grid.x = column chunks, grid.y = j.  256 threads = 32 column lanes (x4 cols) x 8 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(int ni, int D, const T* __restrict__ in, long ld, long base,
+                                                          long si, long sj, float* __restrict__ out, long ldo,
+                                                          float scale, int accumulate) {
+  __shared__ float red[8][128 + 4];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 128 + cl * 4;
+  const long j = blockIdx.y;
+  float a[4] = {0, 0, 0, 0};
+  if (c < D) {
+    for (int i = rl; i < ni; i += 8) {
+      const T* p = in + (base + (long)i * si + j * sj) * ld + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += ET<T>::ld(p + e);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int col = blockIdx.x * 128 + threadIdx.x;
+    if (col < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+      t *= scale;
+      float* o = out + j * ldo + col;
+      *o = accumulate ? *o + t : t;
+    }
+  }
+}
+
+// ---- patch gather: clip [B,T,C,H,W] fp32 -> rows [(b,p,t') or (b,t',p)][K] -----------
+// One thread per (row, c, kt, kh) run of ps contiguous pixels (ps = 16 -> 64 B read).
+template <typename T>
+__global__ void patch_rows_kernel(int B, int Tn, int C, int H, int W, int ps, int ts, const float* __restrict__ clip,
+                                  T* __restrict__ rows, long ldr, int frame_major) {
+  const int gh = H / ps, gw = W / ps, P = gh * gw, Tq = Tn / ts;
+  const long runs_per_row = (long)C * ts * ps;                 // (c, kt, kh)
+  const long total = (long)B * Tq * P * runs_per_row;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // idx -> (b, tq, ph, c, kt, kh, pw): pw fastest so that neighbouring threads read neighbouring pixels
+    long r = idx;
+    const int pw = (int)(r % gw); r /= gw;
+    const int kh = (int)(r % ps); r /= ps;
+    const int kt = (int)(r % ts); r /= ts;
+    const int c = (int)(r % C); r /= C;
+    const int ph = (int)(r % gh); r /= gh;
+    const int tq = (int)(r % Tq); r /= Tq;
+    const int b = (int)r;
+    const float* src = clip + ((((long)b * Tn + (tq * ts + kt)) * C + c) * H + (ph * ps + kh)) * W + pw * ps;
+    const int p = ph * gw + pw;
+    const long row = frame_major ? ((long)b * Tq + tq) * P + p : ((long)b * P + p) * Tq + tq;
+    T* dst = rows + row * ldr + ((long)(c * ts + kt) * ps + kh) * ps;
+    for (int kw = 0; kw < ps; kw += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + kw);
+      ET<T>::st(dst + kw, v.x); ET<T>::st(dst + kw + 1, v.y); ET<T>::st(dst + kw + 2, v.z); ET<T>::st(dst + kw + 3, v.w);
+    }
+  }
+}
+
+// ---- E[(p,t) or (t,p)] = bias + pos[1+p] + time[t];  cls_row = cls + pos[0] -------------
+template <typename T>
+__global__ void embed_table_kernel(int P, int Tn, int D, const float* __restrict__ bias, const float* __restrict__ pos,
+                                   const float* __restrict__ time_embed, const float* __restrict__ cls,
+                                   T* __restrict__ E, T* __restrict__ cls_row, int frame_major) {
+  const long total = ((long)P * Tn + 1) * D;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / D;
+    const int d = (int)(idx - row * D);
+    if (row == (long)P * Tn) {
+      if (cls_row) ET<T>::st(cls_row + d, cls[d] + pos[d]);
+      continue;
+    }
+    int p, t;
+    if (frame_major) { t = (int)(row / P); p = (int)(row - (long)t * P); }
+    else { p = (int)(row / Tn); t = (int)(row - (long)p * Tn); }
+    float v = pos[(long)(1 + p) * D + d];
+    if (bias) v += bias[d];
+    if (time_embed) v += time_embed[(long)t * D + d];
+    ET<T>::st(E + row * D + d, v);
+  }
+}
+
+static inline int grid_for(long work, int block, int cap = 4096) {
+  long g = (work + block - 1) / block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace vtx
+
+using namespace vtx;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, name)              \
+  if ((dtype) == VTX_F32) { CALL_F32; }                           \
+  else if ((dtype) == VTX_BF16) { CALL_BF16; }                    \
+  else VTX_REQUIRE(false, VTX_EINVAL, name ": bad dtype %d", (int)(dtype))
+
+extern "C" int vtx_cast_transpose(int dtype, int R, int C, const float* W, void* Wc, void* WcT, void* stream) {
+  VTX_REQUIRE(R > 0 && C > 0 && W && (Wc || WcT), VTX_EINVAL, "cast_transpose: bad arguments");
+  dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, block, 0, st, R, C, W, (float*)Wc, (float*)WcT),
+             hipLaunchKernelGGL(cast_transpose_kernel<bf16raw>, grid, block, 0, st, R, C, W, (bf16raw*)Wc, (bf16raw*)WcT),
+             "cast_transpose");
+  return check_launch("cast_transpose");
+}
+
+extern "C" int vtx_cast_from_f32(int dtype, size_t n, const float* src, void* dst, void* stream) {
+  VTX_REQUIRE(src && dst, VTX_EINVAL, "cast_from_f32: null pointer");
+  if (n == 0) return VTX_OK;
+  dim3 grid(grid_for((long)n, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<float>, grid, block, 0, st, n, src, (float*)dst),
+             hipLaunchKernelGGL(cast_from_f32_kernel<bf16raw>, grid, block, 0, st, n, src, (bf16raw*)dst), "cast_from_f32");
+  return check_launch("cast_from_f32");
+}
+
+extern "C" int vtx_cast_to_f32(int dtype, size_t n, const void* src, float* dst, void* stream) {
+  VTX_REQUIRE(src && dst, VTX_EINVAL, "cast_to_f32: null pointer");
+  if (n == 0) return VTX_OK;
+  dim3 grid(grid_for((long)n, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_to_f32_kernel<float>, grid, block, 0, st, n, (const float*)src, dst),
+             hipLaunchKernelGGL(cast_to_f32_kernel<bf16raw>, grid, block, 0, st, n, (const bf16raw*)src, dst), "cast_to_f32");
+  return check_launch("cast_to_f32");
+}
+
+extern "C" int vtx_cls_mean_fwd(int dtype, int B, int T, int D, const void* a_cls, long lda, const void* x, void* out,
+                                long ld_tok, long rows_per_clip, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && D > 0 && D % 8 == 0 && a_cls && x && out, VTX_EINVAL, "cls_mean_fwd: bad arguments");
+  dim3 grid(cdiv((long)B * D / 8, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(cls_mean_fwd_kernel<float>, grid, block, 0, st, B, T, D, (const float*)a_cls, lda, (const float*)x, (float*)out, ld_tok, rows_per_clip),
+             hipLaunchKernelGGL(cls_mean_fwd_kernel<bf16raw>, grid, block, 0, st, B, T, D, (const bf16raw*)a_cls, lda, (const bf16raw*)x, (bf16raw*)out, ld_tok, rows_per_clip),
+             "cls_mean_fwd");
+  return check_launch("cls_mean_fwd");
+}
+
+extern "C" int vtx_space_grad_prep(int dtype, int B, int T, int P, int D, const void* dout, long ld, const float* s,
+                                   void* da, long ldda, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && P > 0 && D % 8 == 0 && dout && da, VTX_EINVAL, "space_grad_prep: bad arguments");
+  const long work = ((long)B * P * T + (long)B * T) * (D / 8);
+  dim3 grid(grid_for(work, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(space_grad_prep_kernel<float>, grid, block, 0, st, B, T, P, D, (const float*)dout, ld, s, (float*)da, ldda),
+             hipLaunchKernelGGL(space_grad_prep_kernel<bf16raw>, grid, block, 0, st, B, T, P, D, (const bf16raw*)dout, ld, s, (bf16raw*)da, ldda),
+             "space_grad_prep");
+  return check_launch("space_grad_prep");
+}
+
+extern "C" int vtx_cls_qkv_reduce(int dtype, int B, int T, int W, const void* dqkv_cls, long ldc, void* dqkv, long ld,
+                                  long rows_per_clip, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && W % 8 == 0 && dqkv_cls && dqkv, VTX_EINVAL, "cls_qkv_reduce: bad arguments");
+  dim3 grid(cdiv((long)B * W / 8, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(cls_qkv_reduce_kernel<float>, grid, block, 0, st, B, T, W, (const float*)dqkv_cls, ldc, (float*)dqkv, ld, rows_per_clip),
+             hipLaunchKernelGGL(cls_qkv_reduce_kernel<bf16raw>, grid, block, 0, st, B, T, W, (const bf16raw*)dqkv_cls, ldc, (bf16raw*)dqkv, ld, rows_per_clip),
+             "cls_qkv_reduce");
+  return check_launch("cls_qkv_reduce");
+}
+
+extern "C" int vtx_row_scale_copy(int dtype, int rows, int D, const void* src, long lds, vtx_rowmap smap, void* dst,
+                                  long ldd, vtx_rowmap dmap, const float* s, int rs_d1, int rs_m1, int rs_d2, int rs_m2,
+                                  void* stream) {
+  VTX_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && src && dst, VTX_EINVAL, "row_scale_copy: bad arguments");
+  VTX_REQUIRE(!s || (rs_d1 > 0 && rs_d2 > 0), VTX_EINVAL, "row_scale_copy: divisors must be > 0");
+  dim3 grid(grid_for((long)rows * (D / 8), 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(row_scale_copy_kernel<float>, grid, block, 0, st, rows, D, (const float*)src, lds, smap, (float*)dst, ldd, dmap, s, rs_d1, rs_m1, rs_d2, rs_m2),
+             hipLaunchKernelGGL(row_scale_copy_kernel<bf16raw>, grid, block, 0, st, rows, D, (const bf16raw*)src, lds, smap, (bf16raw*)dst, ldd, dmap, s, rs_d1, rs_m1, rs_d2, rs_m2),
+             "row_scale_copy");
+  return check_launch("row_scale_copy");
+}
+
+extern "C" int vtx_reduce_rows(int in_dtype, int nj, int ni, int D, const void* in, long ld, long base, long si, long sj,
+                               float* out, long ldo, float scale, int accumulate, void* stream) {
+  VTX_REQUIRE(nj > 0 && ni > 0 && D > 0 && D % 4 == 0 && in && out, VTX_EINVAL, "reduce_rows: bad arguments");
+  dim3 grid(cdiv(D, 128), nj), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(in_dtype,
+             hipLaunchKernelGGL(reduce_rows_kernel<float>, grid, block, 0, st, ni, D, (const float*)in, ld, base, si, sj, out, ldo, scale, accumulate),
+             hipLaunchKernelGGL(reduce_rows_kernel<bf16raw>, grid, block, 0, st, ni, D, (const bf16raw*)in, ld, base, si, sj, out, ldo, scale, accumulate),
+             "reduce_rows");
+  return check_launch("reduce_rows");
+}
+
+extern "C" int vtx_patch_rows(int dtype, int B, int T, int C, int H, int W, int ps, int ts, const float* clip, void* rows,
+                              long ldr, int frame_major, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && C > 0 && ps > 0 && ts > 0 && clip && rows, VTX_EINVAL, "patch_rows: bad arguments");
+  VTX_REQUIRE(H % ps == 0 && W % ps == 0 && T % ts == 0 && ps % 4 == 0 && W % 4 == 0, VTX_EINVAL,
+              "patch_rows: H,W must be multiples of ps (itself a multiple of 4), T of ts");
+  const long work = (long)B * (T / ts) * (H / ps) * (W / ps) * C * ts * ps;
+  dim3 grid(grid_for(work, 256, 16384)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(patch_rows_kernel<float>, grid, block, 0, st, B, T, C, H, W, ps, ts, clip, (float*)rows, ldr, frame_major),
+             hipLaunchKernelGGL(patch_rows_kernel<bf16raw>, grid, block, 0, st, B, T, C, H, W, ps, ts, clip, (bf16raw*)rows, ldr, frame_major),
+             "patch_rows");
+  return check_launch("patch_rows");
+}
+
+extern "C" int vtx_embed_table(int dtype, int P, int T, int D, const float* bias, const float* pos, const float* time_embed,
+                               const float* cls, void* E, void* cls_row, int frame_major, void* stream) {
+  VTX_REQUIRE(P > 0 && T > 0 && D > 0 && pos && E, VTX_EINVAL, "embed_table: bad arguments");
+  VTX_REQUIRE(!cls_row || cls, VTX_EINVAL, "embed_table: cls_row needs cls");
+  dim3 grid(grid_for(((long)P * T + 1) * D, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embed_table_kernel<float>, grid, block, 0, st, P, T, D, bias, pos, time_embed, cls, (float*)E, (float*)cls_row, frame_major),
+             hipLaunchKernelGGL(embed_table_kernel<bf16raw>, grid, block, 0, st, P, T, D, bias, pos, time_embed, cls, (bf16raw*)E, (bf16raw*)cls_row, frame_major),
+             "embed_table");
+  return check_launch("embed_table");
+}

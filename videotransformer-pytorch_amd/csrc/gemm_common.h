@@ -1,0 +1,99 @@
+// gemm_common.h -- pieces shared by the NT (forward / dgrad) and TN (wgrad) GEMMs.
+#pragma once
+#include "common.h"
+
+namespace vtx {
+
+constexpr int BM = 128, BN = 128;
+constexpr int STAGE_LD = 68;                               // floats per staged row (64 + 4 pad)
+constexpr int STAGE_BYTES = 4 * 64 * STAGE_LD * 4;         // 69632
+constexpr int NT_THREADS = 256;
+
+struct EpiParams {
+  int M, N;
+  void* C; long ldc; vtx_rowmap cmap;
+  const float* bias;
+  int act; void* C2; long ldc2;
+  const void* dgelu_in; long ld_dgelu;
+  const float* row_scale; int rs_d1, rs_m1, rs_d2, rs_m2;
+  const void* R; long ldr; vtx_rowmap rmap; int r_period;
+  int split_row; void* Csplit; long ldsplit;
+};
+
+// XCD-aware bijective remap of the linear block id (8 XCDs, block b runs on XCD b%8):
+// gives every XCD a contiguous run of logical tiles so neighbouring tiles share L2.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+// Store the wave's 2x2 MFMA 32x32 accumulators (C/D layout: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) into its private fp32 staging tile.
+__device__ inline void stage_acc(float* stage, const f32x16 (&acc)[2][2], int lane) {
+  const int col = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+        stage[row * STAGE_LD + ni * 32 + col] = acc[mi][ni][r];
+      }
+}
+
+template <typename T>
+__device__ inline void epilogue(const EpiParams& p, const float* stage, int m_base, int n_base, int lane) {
+#pragma unroll 1
+  for (int e = 0; e < 8; ++e) {
+    const int rw = e * 8 + (lane >> 3);
+    const int m = m_base + rw;
+    const int n = n_base + (lane & 7) * 8;
+    if (m >= p.M || n >= p.N) continue;
+    float v[8];
+    const float* s = stage + rw * STAGE_LD + (lane & 7) * 8;
+    const float4 s0 = *reinterpret_cast<const float4*>(s);
+    const float4 s1 = *reinterpret_cast<const float4*>(s + 4);
+    v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (p.act == 1) {
+      if (p.C2) store8(reinterpret_cast<T*>(p.C2) + (long)m * p.ldc2 + n, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+    }
+    if (p.dgelu_in) {
+      float h[8];
+      load8(reinterpret_cast<const T*>(p.dgelu_in) + (long)m * p.ld_dgelu + n, h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(h[j]);
+    }
+    const bool split = p.split_row > 0 && m >= p.split_row;
+    if (p.row_scale) {
+      const int idx = split ? (m - p.split_row) : (m / p.rs_d1) * p.rs_m1 + (m % p.rs_d2) * p.rs_m2;
+      const float sc = p.row_scale[idx];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= sc;
+    }
+    if (split) {
+      store8(reinterpret_cast<T*>(p.Csplit) + (long)(m - p.split_row) * p.ldsplit + n, v);
+      continue;
+    }
+    if (p.R) {
+      const long rr = p.r_period > 0 ? (long)(m % p.r_period) : map_row(p.rmap, m);
+      float r8[8];
+      load8(reinterpret_cast<const T*>(p.R) + rr * p.ldr + n, r8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r8[j];
+    }
+    store8(reinterpret_cast<T*>(p.C) + map_row(p.cmap, m) * p.ldc + n, v);
+  }
+}
+
+
+}  // namespace vtx

@@ -1,0 +1,277 @@
+// gemm_nt.hip -- C[M,N] = epilogue(A[M,K] * B[N,K]^T), both operands K-contiguous.
+//
+// Serves every nn.Linear forward and input-gradient on the path (reference
+// transformer.py:160-175 qkv/proj, :225,267 temporal_fc, :498-507 FFN, the
+// Conv2d/Conv3d patch projection :116-126 after vtx_patch_rows, and
+// video_transformer.py:855,878 decoder_pred).  Input gradients use the same
+// kernel with the transposed weight copy made by vtx_cast_transpose.
+//
+// MFMA-bound.  128x128 output tile per 256-thread workgroup (4 waves, 2x2, each
+// 64x64 = 2x2 MFMA 32x32 tiles).
+//   bf16: BK=64, v_mfma_f32_32x32x16_bf16; LDS tiles [128][64] bf16 with the
+//         16-B chunk index XOR-swizzled by (row>>1)&7 so ds_read_b128 fragment
+//         reads are bank-conflict free; register-staged global loads, double-
+//         buffered LDS, one barrier per K tile.
+//   fp32: BK=16, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain); LDS [128][17].
+// Epilogue: accumulators are staged through LDS (wave-private 64x68 fp32) so the
+// fused bias / GELU / GELU' / DropPath-scale / residual / row-scatter run on
+// row-contiguous 8-element vectors, independent of the MFMA register layout.
+// Algorithmic FLOPs per launch: 2*M*N*K.
+#include "gemm_common.h"
+
+namespace vtx {
+
+// ------------------------------------------------------------------ bf16 kernel
+constexpr int BK16 = 64;  // K elements per tile (bf16)
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_kernel(
+    int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][128][64]
+  bf16raw* Bs = As + 2 * BM * BK16;                                  // [2][128][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // loader assignment: 4 chunks of 16 B per operand per thread; rows tid/8 + 32*it, chunk tid%8
+  const int lc = tid & 7, lr = tid >> 3;
+  const bf16raw* ap[4];
+  const bf16raw* bp[4];
+  int lds_off[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = lr + 32 * it;
+    int ma = m0 + row; if (ma >= M) ma = M - 1;
+    int nb = n0 + row; if (nb >= N) nb = N - 1;
+    ap[it] = A + map_row(amap, ma) * lda + lc * 8;
+    bp[it] = B + (long)nb * ldb + lc * 8;
+    lds_off[it] = row * BK16 + ((lc ^ ((row >> 1) & 7)) << 3);
+  }
+  uint4 ra[4], rb[4];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define GLOAD16(k0_)                                                                  \
+  {                                                                                   \
+    const int k0__ = (k0_);                                                           \
+    const bool ok = (k0__ + lc * 8) < K;                                              \
+    const int ko__ = ok ? k0__ : 0; /* always-valid address; zeroed below */          \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                \
+      ra[it] = *reinterpret_cast<const uint4*>(ap[it] + ko__);                        \
+      rb[it] = *reinterpret_cast<const uint4*>(bp[it] + ko__);                        \
+      if (!ok) { ra[it] = zero4; rb[it] = zero4; }                                    \
+    }                                                                                 \
+  }
+#define LSTORE16(buf_)                                                                \
+  {                                                                                   \
+    const int b__ = (buf_);                                                           \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                \
+      *reinterpret_cast<uint4*>(As + b__ * BM * BK16 + lds_off[it]) = ra[it];         \
+      *reinterpret_cast<uint4*>(Bs + b__ * BN * BK16 + lds_off[it]) = rb[it];         \
+    }                                                                                 \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (elements) for this lane; chunk = ks*2 + (lane>>5)
+  int a_row_off[2], b_row_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ar = wm * 64 + i * 32 + (lane & 31);
+    const int br = wn * 64 + i * 32 + (lane & 31);
+    a_row_off[i] = ar * BK16; a_sw[i] = (ar >> 1) & 7;
+    b_row_off[i] = br * BK16; b_sw[i] = (br >> 1) & 7;
+  }
+  const int khalf = lane >> 5;
+
+  const int nk = (K + BK16 - 1) / BK16;
+  GLOAD16(0);
+  LSTORE16(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) GLOAD16((kt + 1) * BK16);
+    const bf16raw* Ab = As + buf * BM * BK16;
+    const bf16raw* Bb = Bs + buf * BN * BK16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + khalf;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row_off[i] + ((c ^ a_sw[i]) << 3));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(Bb + b_row_off[i] + ((c ^ b_sw[i]) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) LSTORE16(buf ^ 1);
+    __syncthreads();
+  }
+#undef GLOAD16
+#undef LSTORE16
+  float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stage, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private staging, no barrier needed
+  __builtin_amdgcn_wave_barrier();
+  epilogue<bf16raw>(ep, stage, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------ fp32 kernel
+constexpr int BK32 = 16;
+constexpr int LD32 = BK32 + 1;
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_f32_kernel(
+    int M, int N, int K, const float* __restrict__ A, long lda, vtx_rowmap amap,
+    const float* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);        // [2][128][17]
+  float* Bs = As + 2 * BM * LD32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // loader: 128 rows x 4 float4 chunks = 512 chunks -> 2 per thread per operand
+  const int lc = tid & 3, lr = tid >> 2;
+  const float* ap[2];
+  const float* bp[2];
+  int lds_off[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = lr + 64 * it;
+    int ma = m0 + row; if (ma >= M) ma = M - 1;
+    int nb = n0 + row; if (nb >= N) nb = N - 1;
+    ap[it] = A + map_row(amap, ma) * lda + lc * 4;
+    bp[it] = B + (long)nb * ldb + lc * 4;
+    lds_off[it] = row * LD32 + lc * 4;
+  }
+  float4 ra[2], rb[2];
+#define GLOAD32(k0_)                                                                          \
+  {                                                                                           \
+    const int k0__ = (k0_);                                                                   \
+    const bool ok = (k0__ + lc * 4) < K;                                                      \
+    const int ko__ = ok ? k0__ : 0;                                                           \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                        \
+      ra[it] = *reinterpret_cast<const float4*>(ap[it] + ko__);                               \
+      rb[it] = *reinterpret_cast<const float4*>(bp[it] + ko__);                               \
+      if (!ok) { ra[it] = make_float4(0, 0, 0, 0); rb[it] = make_float4(0, 0, 0, 0); }        \
+    }                                                                                         \
+  }
+#define LSTORE32(buf_)                                                                        \
+  {                                                                                           \
+    const int b__ = (buf_);                                                                   \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                        \
+      float* a = As + b__ * BM * LD32 + lds_off[it];                                          \
+      a[0] = ra[it].x; a[1] = ra[it].y; a[2] = ra[it].z; a[3] = ra[it].w;                     \
+      float* b = Bs + b__ * BN * LD32 + lds_off[it];                                          \
+      b[0] = rb[it].x; b[1] = rb[it].y; b[2] = rb[it].z; b[3] = rb[it].w;                     \
+    }                                                                                         \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a_off[i] = (wm * 64 + i * 32 + (lane & 31)) * LD32 + (lane >> 5);
+    b_off[i] = (wn * 64 + i * 32 + (lane & 31)) * LD32 + (lane >> 5);
+  }
+
+  const int nk = (K + BK32 - 1) / BK32;
+  GLOAD32(0);
+  LSTORE32(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) GLOAD32((kt + 1) * BK32);
+    const float* Ab = As + buf * BM * LD32;
+    const float* Bb = Bs + buf * BN * LD32;
+#pragma unroll
+    for (int ks = 0; ks < BK32 / 2; ++ks) {
+      float af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { af[i] = Ab[a_off[i] + ks * 2]; bfr[i] = Bb[b_off[i] + ks * 2]; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) LSTORE32(buf ^ 1);
+    __syncthreads();
+  }
+#undef GLOAD32
+#undef LSTORE32
+  float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stage, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  epilogue<float>(ep, stage, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+}  // namespace vtx
+
+using namespace vtx;
+
+extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
+  VTX_REQUIRE(d != nullptr, VTX_EINVAL, "gemm_nt: null descriptor");
+  VTX_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0, VTX_EINVAL, "gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  if (d->M == 0) return VTX_OK;
+  VTX_REQUIRE(d->N % 8 == 0 && d->K % 8 == 0, VTX_EINVAL, "gemm_nt: N=%d and K=%d must be multiples of 8", d->N, d->K);
+  VTX_REQUIRE(d->A && d->B && d->C, VTX_EINVAL, "gemm_nt: null operand");
+  VTX_REQUIRE(d->dtype == VTX_F32 || d->dtype == VTX_BF16, VTX_EINVAL, "gemm_nt: bad dtype %d", d->dtype);
+  const long vec = d->dtype == VTX_BF16 ? 8 : 4;
+  VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C) && d->lda % vec == 0 && d->ldb % vec == 0 &&
+                  d->ldc % vec == 0, VTX_EALIGN, "gemm_nt: operands must be 16-byte aligned");
+  VTX_REQUIRE(!d->bias || aligned16(d->bias), VTX_EALIGN, "gemm_nt: bias not aligned");
+  VTX_REQUIRE(!d->R || (aligned16(d->R) && d->ldr % vec == 0), VTX_EALIGN, "gemm_nt: residual not aligned");
+  VTX_REQUIRE(!(d->act == 1 && d->C2) || (aligned16(d->C2) && d->ldc2 % vec == 0), VTX_EALIGN, "gemm_nt: C2 not aligned");
+  VTX_REQUIRE(!d->dgelu_in || (aligned16(d->dgelu_in) && d->ld_dgelu % vec == 0), VTX_EALIGN, "gemm_nt: dgelu_in not aligned");
+  VTX_REQUIRE(d->split_row <= 0 || (d->Csplit && aligned16(d->Csplit) && d->ldsplit % vec == 0), VTX_EINVAL,
+              "gemm_nt: split_row needs an aligned Csplit");
+  VTX_REQUIRE(!d->row_scale || (d->rs_d1 > 0 && d->rs_d2 > 0), VTX_EINVAL, "gemm_nt: row_scale divisors must be > 0");
+  VTX_REQUIRE(d->act == 0 || d->act == 1, VTX_EINVAL, "gemm_nt: bad act %d", d->act);
+
+  EpiParams ep;
+  ep.M = d->M; ep.N = d->N;
+  ep.C = d->C; ep.ldc = d->ldc; ep.cmap = d->cmap;
+  ep.bias = d->bias; ep.act = d->act; ep.C2 = d->C2; ep.ldc2 = d->ldc2;
+  ep.dgelu_in = d->dgelu_in; ep.ld_dgelu = d->ld_dgelu;
+  ep.row_scale = d->row_scale; ep.rs_d1 = d->rs_d1; ep.rs_m1 = d->rs_m1; ep.rs_d2 = d->rs_d2; ep.rs_m2 = d->rs_m2;
+  ep.R = d->R; ep.ldr = d->ldr; ep.rmap = d->rmap; ep.r_period = d->r_period;
+  ep.split_row = d->split_row; ep.Csplit = d->Csplit; ep.ldsplit = d->ldsplit;
+
+  const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
+  dim3 grid(tiles_m * tiles_n), block(NT_THREADS);
+  hipStream_t st = as_stream(stream);
+  if (d->dtype == VTX_BF16) {
+    const size_t lds = STAGE_BYTES > 4 * BM * BK16 * 2 ? STAGE_BYTES : 4 * BM * BK16 * 2;
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
+                       d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
+  } else {
+    const size_t need = (size_t)4 * BM * LD32 * 4;
+    const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, block, lds, st, d->M, d->N, d->K, (const float*)d->A, d->lda,
+                       d->amap, (const float*)d->B, d->ldb, tiles_n, ep);
+  }
+  return check_launch("gemm_nt");
+}

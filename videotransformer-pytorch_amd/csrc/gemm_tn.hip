@@ -1,0 +1,359 @@
+// gemm_tn.hip -- weight gradients: C[N1,N2] (fp32) (+)= sum_m A[m][n1] * B[m][n2].
+//
+// Replaces autograd's mm(grad_out^T, input) for every nn.Linear on the path
+// (reference transformer.py:160,162,225,501,505; patch projection :116-126;
+// video_transformer.py:855).  The reduction runs over the token rows M, which
+// are NOT contiguous for either operand, so the MFMA operand fragments are
+// transposed reads of row-major LDS tiles:
+//   bf16: tiles [64 m][128 n] bf16 (row stride 160 elements = 320 B so that the
+//         4 rows x 64 B touched by each half-wave of ds_read_b64_tr_b16 fall in
+//         four disjoint bank quarters); the hardware transpose read
+//         ds_read_b64_tr_b16 delivers 4 consecutive-m values of one column per
+//         lane, two reads build the 8-deep K fragment of v_mfma_f32_32x32x16_bf16.
+//         VTX_TN_SAFE=1 selects plain 2-byte LDS gathers instead (slow, no
+//         dependence on the tr instruction) -- kept as a diagnostic path.
+//   fp32: tiles [16 m][128 n]; v_mfma_f32_32x32x2_f32 takes one element per lane,
+//         read straight along the row (conflict free, no transpose needed).
+// M is split over `splits` workgroup slices (fp32 slabs in the workspace) that a
+// second kernel sums in a fixed order: deterministic, no atomics.
+// Algorithmic FLOPs per launch: 2*M*N1*N2.
+#include <stdlib.h>
+#include "gemm_common.h"
+
+namespace vtx {
+
+int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
+                           int accumulate, float scale, hipStream_t st);
+
+constexpr int TN_BKM = 64;        // m rows per tile (bf16)
+constexpr int TN_LD = 160;        // padded row length (bf16 elements)
+constexpr int TN_BKM32 = 16;      // m rows per tile (fp32)
+constexpr int TN_LD32 = 128;
+
+struct TnOut {
+  float* slab; long slab_stride;  // [splits][N1*N2]
+  int N1, N2;
+};
+
+__device__ inline void tn_store(const TnOut& o, const float* stage, int split, int r_base, int c_base, int lane) {
+  float* dst = o.slab + (long)split * o.slab_stride;
+#pragma unroll 1
+  for (int e = 0; e < 8; ++e) {
+    const int rw = e * 8 + (lane >> 3);
+    const int r = r_base + rw, c = c_base + (lane & 7) * 8;
+    if (r >= o.N1 || c >= o.N2) continue;
+    const float* s = stage + rw * STAGE_LD + (lane & 7) * 8;
+    float* d = dst + (long)r * o.N2 + c;
+    *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(s);
+    *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(s + 4);
+  }
+}
+
+template <bool SAFE>
+__global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_kernel(
+    int M, int m_per_split, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* As = reinterpret_cast<bf16raw*>(smem);          // [64][160]
+  bf16raw* Bs = As + TN_BKM * TN_LD;                       // [64][160]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x / tiles12;
+  const int tile = blockIdx.x - split * tiles12;
+  const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+  const int r0 = t1 * 128, c0 = t2 * 128;               // output tile origin (n1, n2)
+  const int m_begin = split * m_per_split;
+  const int m_end = min(M, m_begin + m_per_split);
+
+  // loader: 64 rows x 16 chunks(16 B) = 1024 chunks -> 4 per thread per operand
+  const int lc = tid & 15, lr = tid >> 4;
+  const bool a_col_ok = (r0 + lc * 8) < out.N1;
+  const bool b_col_ok = (c0 + lc * 8) < out.N2;
+  const int a_col = a_col_ok ? r0 + lc * 8 : 0;
+  const int b_col = b_col_ok ? c0 + lc * 8 : 0;
+  uint4 ra[4], rb[4];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define TN_GLOAD16(mt_)                                                                                          \
+  {                                                                                                              \
+    const int mt__ = (mt_);                                                                                      \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                           \
+      const int m = mt__ + lr + 16 * it;                                                                         \
+      const bool ok = m < m_end;                                                                                 \
+      const int mc = m < M ? m : M - 1; /* always-valid address; zeroed below */                                 \
+      ra[it] = *reinterpret_cast<const uint4*>(A + map_row(amap, mc) * lda + a_col);                             \
+      rb[it] = *reinterpret_cast<const uint4*>(B + map_row(bmap, mc) * ldb + b_col);                             \
+      if (!(ok && a_col_ok)) ra[it] = zero4;                                                                     \
+      if (!(ok && b_col_ok)) rb[it] = zero4;                                                                     \
+    }                                                                                                            \
+  }
+#define TN_LSTORE16()                                                  \
+  {                                                                    \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                 \
+      const int off = (lr + 16 * it) * TN_LD + lc * 8;                 \
+      *reinterpret_cast<uint4*>(As + off) = ra[it];                    \
+      *reinterpret_cast<uint4*>(Bs + off) = rb[it];                    \
+    }                                                                  \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Transposed fragment addressing.  MFMA operand: lane l holds column (l&31) of
+  // the 32-wide tile for k = 8*(l>>5) + j, j = 0..7.  ds_read_b64_tr_b16: in
+  // each 16-lane group, lane r supplies the address of 4 contiguous elements of
+  // row (r>>2), columns 4*(r&3)..+3 of a [4][16] block; lane i receives column i.
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int sf_row = 8 * (lane >> 5);           // SAFE path: own column, 8 rows
+  const int sf_col = lane & 31;
+
+  TN_GLOAD16(m_begin);
+  for (int mt = m_begin; mt < m_end; mt += TN_BKM) {
+    TN_LSTORE16();
+    __syncthreads();
+    if (mt + TN_BKM < m_end) TN_GLOAD16(mt + TN_BKM);
+#pragma unroll
+    for (int ks = 0; ks < TN_BKM / 16; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (SAFE) {
+          const bf16raw* pa = As + (ks * 16 + sf_row) * TN_LD + wm * 64 + i * 32 + sf_col;
+          const bf16raw* pb = Bs + (ks * 16 + sf_row) * TN_LD + wn * 64 + i * 32 + sf_col;
+          union { bf16x8 v; bf16raw s[8]; } ua, ub;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ua.s[j] = pa[j * TN_LD]; ub.s[j] = pb[j * TN_LD]; }
+          af[i] = ua.v; bfr[i] = ub.v;
+        } else {
+          const bf16raw* pa = As + (ks * 16 + tr_row) * TN_LD + wm * 64 + i * 32 + tr_col;
+          const bf16raw* pb = Bs + (ks * 16 + tr_row) * TN_LD + wn * 64 + i * 32 + tr_col;
+          union { bf16x8 v; s16x4 h[2]; } ua, ub;
+          ua.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+          ua.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * TN_LD));
+          ub.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+          ub.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * TN_LD));
+          af[i] = ua.v; bfr[i] = ub.v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stage, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  tn_store(out, stage, split, r0 + wm * 64, c0 + wn * 64, lane);
+}
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_tn_f32_kernel(
+    int M, int m_per_split, const float* __restrict__ A, long lda, vtx_rowmap amap,
+    const float* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);              // [16][128]
+  float* Bs = As + TN_BKM32 * TN_LD32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x / tiles12;
+  const int tile = blockIdx.x - split * tiles12;
+  const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+  const int r0 = t1 * 128, c0 = t2 * 128;
+  const int m_begin = split * m_per_split;
+  const int m_end = min(M, m_begin + m_per_split);
+
+  // loader: 16 rows x 32 float4 chunks = 512 chunks -> 2 per thread per operand
+  const int lc = tid & 31, lr = tid >> 5;
+  const bool a_col_ok = (r0 + lc * 4) < out.N1;
+  const bool b_col_ok = (c0 + lc * 4) < out.N2;
+  const int a_col = a_col_ok ? r0 + lc * 4 : 0;
+  const int b_col = b_col_ok ? c0 + lc * 4 : 0;
+  float4 ra[2], rb[2];
+  const float4 z4 = make_float4(0, 0, 0, 0);
+#define TN_GLOAD32(mt_)                                                                                        \
+  {                                                                                                            \
+    const int mt__ = (mt_);                                                                                    \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                         \
+      const int m = mt__ + lr + 8 * it;                                                                        \
+      const bool ok = m < m_end;                                                                               \
+      const int mc = m < M ? m : M - 1;                                                                        \
+      ra[it] = *reinterpret_cast<const float4*>(A + map_row(amap, mc) * lda + a_col);                          \
+      rb[it] = *reinterpret_cast<const float4*>(B + map_row(bmap, mc) * ldb + b_col);                          \
+      if (!(ok && a_col_ok)) ra[it] = z4;                                                                      \
+      if (!(ok && b_col_ok)) rb[it] = z4;                                                                      \
+    }                                                                                                          \
+  }
+#define TN_LSTORE32()                                                  \
+  {                                                                    \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                 \
+      const int off = (lr + 8 * it) * TN_LD32 + lc * 4;                \
+      *reinterpret_cast<float4*>(As + off) = ra[it];                   \
+      *reinterpret_cast<float4*>(Bs + off) = rb[it];                   \
+    }                                                                  \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kh = lane >> 5, col = lane & 31;
+  TN_GLOAD32(m_begin);
+  for (int mt = m_begin; mt < m_end; mt += TN_BKM32) {
+    TN_LSTORE32();
+    __syncthreads();
+    if (mt + TN_BKM32 < m_end) TN_GLOAD32(mt + TN_BKM32);
+#pragma unroll
+    for (int ks = 0; ks < TN_BKM32 / 2; ++ks) {
+      float af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = As[(ks * 2 + kh) * TN_LD32 + wm * 64 + i * 32 + col];
+        bfr[i] = Bs[(ks * 2 + kh) * TN_LD32 + wn * 64 + i * 32 + col];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stage, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  tn_store(out, stage, split, r0 + wm * 64, c0 + wn * 64, lane);
+}
+
+// ---- column sums (bias gradients): part[blk][N] then reduce -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, int rows_per_blk, const T* __restrict__ A,
+                                                     long lda, vtx_rowmap amap, float* __restrict__ part) {
+  // block = 256 threads: 32 column-chunks (8 elements) x 8 row lanes; grid.x = column groups of 256, grid.y = row blocks
+  __shared__ float red[8][256 + 8];
+  const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 256 + cc * 8;
+  const long m0 = (long)blockIdx.y * rows_per_blk;
+  const long m1 = min((long)M, m0 + rows_per_blk);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < N) {
+    for (long m = m0 + rl; m < m1; m += 8) {
+      float v[8];
+      load8(A + map_row(amap, m) * lda + n, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cc * 8 + j] = acc[j];
+  __syncthreads();
+  const int c = threadIdx.x;
+  const int ncol = blockIdx.x * 256 + c;
+  if (ncol < N) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a += red[r][c];
+    part[(long)blockIdx.y * N + ncol] = a;
+  }
+}
+
+static int tn_splits(int M, int N1, int N2) {
+  const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
+  int s = cdiv(768, tiles);                    // ~3 workgroups per CU over 256 CUs
+  const int max_s = M / 256 > 0 ? M / 256 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+static int colsum_blocks(int M) {
+  int b = cdiv(M, 256);
+  return b > 256 ? 256 : (b < 1 ? 1 : b);
+}
+
+}  // namespace vtx
+
+using namespace vtx;
+
+extern "C" size_t vtx_gemm_tn_workspace(int M, int N1, int N2) {
+  return (size_t)tn_splits(M, N1, N2) * (size_t)N1 * (size_t)N2 * sizeof(float);
+}
+
+extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
+  VTX_REQUIRE(d != nullptr, VTX_EINVAL, "gemm_tn: null descriptor");
+  VTX_REQUIRE(d->M > 0 && d->N1 > 0 && d->N2 > 0, VTX_EINVAL, "gemm_tn: bad shape");
+  VTX_REQUIRE(d->N1 % 8 == 0 && d->N2 % 8 == 0, VTX_EINVAL, "gemm_tn: N1=%d, N2=%d must be multiples of 8", d->N1, d->N2);
+  VTX_REQUIRE(d->A && d->B && d->C && d->workspace, VTX_EINVAL, "gemm_tn: null pointer");
+  VTX_REQUIRE(d->ldc == d->N2, VTX_EINVAL, "gemm_tn: C must be contiguous (ldc == N2)");
+  VTX_REQUIRE(d->dtype == VTX_F32 || d->dtype == VTX_BF16, VTX_EINVAL, "gemm_tn: bad dtype");
+  const long vec = d->dtype == VTX_BF16 ? 8 : 4;
+  VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C) && aligned16(d->workspace) &&
+                  d->lda % vec == 0 && d->ldb % vec == 0, VTX_EALIGN, "gemm_tn: 16-byte alignment required");
+  VTX_REQUIRE(d->ws_bytes >= vtx_gemm_tn_workspace(d->M, d->N1, d->N2), VTX_EWS, "gemm_tn: workspace too small");
+
+  const int splits = tn_splits(d->M, d->N1, d->N2);
+  const int tile_m = d->dtype == VTX_BF16 ? TN_BKM : TN_BKM32;
+  int m_per = cdiv(d->M, splits);
+  m_per = cdiv(m_per, tile_m) * tile_m;
+  const int tiles1 = cdiv(d->N1, 128), tiles2 = cdiv(d->N2, 128);
+  TnOut out;
+  out.slab = (float*)d->workspace; out.slab_stride = (long)d->N1 * d->N2; out.N1 = d->N1; out.N2 = d->N2;
+  dim3 grid(tiles1 * tiles2 * splits), block(NT_THREADS);
+  hipStream_t st = as_stream(stream);
+  if (d->dtype == VTX_BF16) {
+    const size_t need = (size_t)2 * TN_BKM * TN_LD * 2;
+    const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;
+    static const bool safe = getenv("VTX_TN_SAFE") && atoi(getenv("VTX_TN_SAFE")) != 0;
+    if (safe)
+      hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, block, lds, st, d->M, m_per, (const bf16raw*)d->A, d->lda,
+                         d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1 * tiles2, out);
+    else
+      hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, block, lds, st, d->M, m_per, (const bf16raw*)d->A, d->lda,
+                         d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1 * tiles2, out);
+  } else {
+    const size_t need = (size_t)2 * TN_BKM32 * TN_LD32 * 4;
+    const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, lds, st, d->M, m_per, (const float*)d->A, d->lda, d->amap,
+                       (const float*)d->B, d->ldb, d->bmap, tiles2, tiles1 * tiles2, out);
+  }
+  int rc = check_launch("gemm_tn");
+  if (rc) return rc;
+  return launch_reduce_partials(out.slab, splits, out.slab_stride, out.slab_stride, d->C, d->accumulate, 1.0f, st);
+}
+
+extern "C" size_t vtx_colsum_workspace(int M, int N) {
+  return (size_t)colsum_blocks(M) * (size_t)N * sizeof(float);
+}
+
+extern "C" int vtx_colsum(int dtype, int M, int N, const void* A, long lda, vtx_rowmap amap, float* out,
+                          int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+  VTX_REQUIRE(M > 0 && N > 0 && N % 8 == 0, VTX_EINVAL, "colsum: bad shape M=%d N=%d", M, N);
+  VTX_REQUIRE(A && out && workspace, VTX_EINVAL, "colsum: null pointer");
+  VTX_REQUIRE(ws_bytes >= vtx_colsum_workspace(M, N), VTX_EWS, "colsum: workspace too small");
+  const long vec = dtype == VTX_BF16 ? 8 : 4;
+  VTX_REQUIRE(aligned16(A) && lda % vec == 0, VTX_EALIGN, "colsum: 16-byte alignment required");
+  const int nb = colsum_blocks(M);
+  const int rows_per = cdiv(M, nb);
+  dim3 grid(cdiv(N, 256), nb), block(256);
+  hipStream_t st = as_stream(stream);
+  if (dtype == VTX_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, M, N, rows_per, (const float*)A, lda, amap, (float*)workspace);
+  else if (dtype == VTX_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16raw>, grid, block, 0, st, M, N, rows_per, (const bf16raw*)A, lda, amap, (float*)workspace);
+  else
+    VTX_REQUIRE(false, VTX_EINVAL, "colsum: bad dtype %d", dtype);
+  int rc = check_launch("colsum");
+  if (rc) return rc;
+  return launch_reduce_partials((const float*)workspace, nb, N, N, out, accumulate, 1.0f, st);
+}

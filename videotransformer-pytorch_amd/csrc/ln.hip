@@ -1,0 +1,296 @@
+// ln.hip -- LayerNorm forward / backward (HBM-bound; one wave64 per row).
+//
+// Reference: nn.LayerNorm instances transformer.py:215,321,418,495 (eps 1e-5)
+// and video_transformer.py:119,401 (eps 1e-6).  Statistics in fp32, biased
+// variance.  Algorithmic bytes per row: read D + write D elements (+8 B stats).
+//
+// Layout: lane l owns elements {4*(l + 64*c) .. +3 : c < NCH}; a wave load is a
+// fully coalesced 64 x (4 elements) segment.  Row reductions are xor-shuffles.
+#include "common.h"
+
+namespace vtx {
+
+template <typename T> __device__ inline void ld4(const T* p, float (&v)[4]);
+template <> __device__ inline void ld4<float>(const float* p, float (&v)[4]) {
+  float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ inline void ld4<bf16raw>(const bf16raw* p, float (&v)[4]) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <typename T> __device__ inline void st4(T* p, const float (&v)[4]);
+template <> __device__ inline void st4<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ inline void st4<bf16raw>(bf16raw* p, const float (&v)[4]) {
+  uint2 r;
+  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+
+constexpr int LN_WAVES = 4;
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
+    int rows, int D, const T* __restrict__ x, long ldx, vtx_rowmap xmap,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    T* __restrict__ y, long ldy, vtx_rowmap ymap, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long total_waves = (long)gridDim.x * LN_WAVES;
+  const float invD = 1.0f / (float)D;
+  for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += total_waves) {
+    const T* xr = x + map_row(xmap, r) * ldx;
+    float v[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (col < D) {
+        ld4<T>(xr + col, v[c]);
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+      } else {
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+      }
+    }
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (col < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mu; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+    T* yr = y + map_row(ymap, r) * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (col < D) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + col);
+        const float4 b = *reinterpret_cast<const float4*>(beta + col);
+        float o[4];
+        o[0] = (v[c][0] - mu) * rstd * g.x + b.x;
+        o[1] = (v[c][1] - mu) * rstd * g.y + b.y;
+        o[2] = (v[c][2] - mu) * rstd * g.z + b.z;
+        o[3] = (v[c][3] - mu) * rstd * g.w + b.w;
+        st4<T>(yr + col, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[r] = mu;
+      if (rstd_out) rstd_out[r] = rstd;
+    }
+  }
+}
+
+// Backward.  Each wave walks rows r = w, w + W, ...; per-lane column partials of
+// dgamma/dbeta stay in registers, are combined across the block's 4 waves in
+// LDS and written to part[block][2][D]; reduce_partials_kernel finishes.
+template <typename T, int NCH>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(
+    int rows, int D, const T* __restrict__ dy, long lddy, vtx_rowmap dymap,
+    const T* __restrict__ x, long ldx, vtx_rowmap xmap, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ dres,
+    T* __restrict__ dx, long lddx, float* __restrict__ part) {
+  __shared__ float red[LN_WAVES][2][NCH * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long total_waves = (long)gridDim.x * LN_WAVES;
+  const float invD = 1.0f / (float)D;
+  float dg[NCH][4], db[NCH][4], gm[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = 4 * (lane + 64 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; gm[c][j] = (col < D) ? gamma[col + j] : 0.f; }
+  }
+  for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += total_waves) {
+    const long pr = map_row(xmap, r);
+    const T* xr = x + pr * ldx;
+    const T* dyr = dy + map_row(dymap, r) * lddy;
+    const float mu = mean[r], rs = rstd[r];
+    float xh[NCH][4], g[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (col < D) {
+        float xv[4], dv[4];
+        ld4<T>(xr + col, xv);
+        ld4<T>(dyr + col, dv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[c][j] = (xv[j] - mu) * rs;
+          g[c][j] = dv[j] * gm[c][j];
+          s1 += g[c][j];
+          s2 += g[c][j] * xh[c][j];
+          dg[c][j] += dv[j] * xh[c][j];
+          db[c][j] += dv[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xh[c][j] = 0.f; g[c][j] = 0.f; }
+      }
+    }
+    const float c1 = wave_sum(s1) * invD;
+    const float c2 = wave_sum(s2) * invD;
+    T* dxr = dx + pr * lddx;
+    const T* drr = dres ? dres + pr * lddx : nullptr;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (col < D) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (g[c][j] - c1 - xh[c][j] * c2);
+        if (drr) {
+          float rv[4];
+          ld4<T>(drr + col, rv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += rv[j];
+        }
+        st4<T>(dxr + col, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][4 * (lane + 64 * c) + j] = dg[c][j];
+      red[wave][1][4 * (lane + 64 * c) + j] = db[c][j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += LN_WAVES * 64) {
+    const int which = i / D, col = i - which * D;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < LN_WAVES; ++w) a += red[w][which][col];
+    part[((long)blockIdx.x * 2 + which) * D + col] = a;
+  }
+}
+
+// out[n] (+)= sum_s part[s*stride + n], n < N.
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nslabs, long stride,
+                                       long N, float* __restrict__ out, int accumulate, float scale) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f;
+  for (int s = 0; s < nslabs; ++s) a += part[(long)s * stride + n];
+  a *= scale;
+  out[n] = accumulate ? out[n] + a : a;
+}
+
+int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
+                           int accumulate, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, nslabs,
+                     stride, N, out, accumulate, scale);
+  return check_launch("reduce_partials");
+}
+
+static int ln_blocks(int rows) {
+  int b = cdiv(rows, LN_WAVES);
+  return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
+
+template <typename T>
+static int ln_fwd_t(int rows, int D, const void* x, long ldx, vtx_rowmap xmap, const float* gamma,
+                    const float* beta, float eps, void* y, long ldy, vtx_rowmap ymap, float* mean,
+                    float* rstd, hipStream_t st) {
+  const int nch = cdiv(D, 256);
+  dim3 g(ln_blocks(rows)), b(LN_WAVES * 64);
+#define LN_FWD(N)                                                                                  \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, N>), g, b, 0, st, rows, D, (const T*)x, ldx, xmap, gamma,   \
+                     beta, eps, (T*)y, ldy, ymap, mean, rstd)
+  switch (nch) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    case 4: LN_FWD(4); break;
+    case 5: case 6: LN_FWD(6); break;
+    default: LN_FWD(8); break;
+  }
+#undef LN_FWD
+  return check_launch("layernorm_fwd");
+}
+
+template <typename T>
+static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap, const void* x,
+                    long ldx, vtx_rowmap xmap, const float* mean, const float* rstd,
+                    const float* gamma, const void* dres, void* dx, long lddx, float* part,
+                    int nblocks, hipStream_t st) {
+  const int nch = cdiv(D, 256);
+  dim3 g(nblocks), b(LN_WAVES * 64);
+#define LN_BWD(N)                                                                                  \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, N>), g, b, 0, st, rows, D, (const T*)dy, lddy, dymap,       \
+                     (const T*)x, ldx, xmap, mean, rstd, gamma, (const T*)dres, (T*)dx, lddx, part)
+  switch (nch) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    case 4: LN_BWD(4); break;
+    case 5: case 6: LN_BWD(6); break;
+    default: LN_BWD(8); break;
+  }
+#undef LN_BWD
+  return check_launch("layernorm_bwd");
+}
+
+}  // namespace vtx
+
+using namespace vtx;
+
+extern "C" int vtx_layernorm_fwd(int dtype, int rows, int D, const void* x, long ldx,
+                                 vtx_rowmap xmap, const float* gamma, const float* beta, float eps,
+                                 void* y, long ldy, vtx_rowmap ymap, float* mean, float* rstd,
+                                 void* stream) {
+  VTX_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0 && D <= 2048, VTX_EINVAL,
+              "layernorm_fwd: D=%d must be a multiple of 4 and <= 2048", D);
+  if (rows == 0) return VTX_OK;
+  VTX_REQUIRE(x && y && gamma && beta, VTX_EINVAL, "layernorm_fwd: null pointer");
+  VTX_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && ldx % 4 == 0 &&
+                  ldy % 4 == 0, VTX_EALIGN, "layernorm_fwd: 16-byte alignment required");
+  if (dtype == VTX_F32)
+    return ln_fwd_t<float>(rows, D, x, ldx, xmap, gamma, beta, eps, y, ldy, ymap, mean, rstd, as_stream(stream));
+  if (dtype == VTX_BF16)
+    return ln_fwd_t<bf16raw>(rows, D, x, ldx, xmap, gamma, beta, eps, y, ldy, ymap, mean, rstd, as_stream(stream));
+  VTX_REQUIRE(false, VTX_EINVAL, "layernorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" size_t vtx_layernorm_bwd_workspace(int rows, int D) {
+  return (size_t)ln_blocks(rows) * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy,
+                                 vtx_rowmap dymap, const void* x, long ldx, vtx_rowmap xmap,
+                                 const float* mean, const float* rstd, const float* gamma,
+                                 const void* dres, void* dx, long lddx, float* dgamma, float* dbeta,
+                                 void* workspace, size_t ws_bytes, void* stream) {
+  VTX_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, VTX_EINVAL, "layernorm_bwd: bad shape");
+  VTX_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, VTX_EINVAL,
+              "layernorm_bwd: null pointer");
+  VTX_REQUIRE(ws_bytes >= vtx_layernorm_bwd_workspace(rows, D), VTX_EWS, "layernorm_bwd: workspace too small");
+  VTX_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
+              VTX_EALIGN, "layernorm_bwd: 16-byte alignment required");
+  const int nb = ln_blocks(rows);
+  float* part = (float*)workspace;
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (dtype == VTX_F32)
+    rc = ln_bwd_t<float>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, st);
+  else if (dtype == VTX_BF16)
+    rc = ln_bwd_t<bf16raw>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, st);
+  else
+    VTX_REQUIRE(false, VTX_EINVAL, "layernorm_bwd: bad dtype %d", dtype);
+  if (rc) return rc;
+  // part layout: [block][2][D] -> dgamma = sum_b part[b][0], dbeta = sum_b part[b][1]
+  rc = launch_reduce_partials(part, nb, 2L * D, D, dgamma, 1, 1.0f, st);
+  if (rc) return rc;
+  return launch_reduce_partials(part + D, nb, 2L * D, D, dbeta, 1, 1.0f, st);
+}

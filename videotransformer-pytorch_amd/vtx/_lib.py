@@ -1,0 +1,146 @@
+"""ctypes binding of libvtx.so (include/vtx.h).  No torch types cross this boundary:
+only raw device pointers, sizes and the HIP stream handle.
+
+The library is looked up next to this package (videotransformer-pytorch_amd/
+libvtx.so, built by csrc/build.py).  There is NO fallback: if it is missing or a
+symbol is absent, importing the ops raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.environ.get('VTX_LIB', os.path.join(_PKG, 'libvtx.so'))
+
+VTX_F32, VTX_BF16 = 0, 1
+ATTN_CONTIG, ATTN_SPACE = 0, 1
+
+
+class RowMap(C.Structure):
+    _fields_ = [('grp', C.c_int), ('skip', C.c_int), ('base', C.c_int)]
+
+
+IDENT = RowMap(0, 0, 0)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ('dtype', C.c_int), ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
+        ('A', C.c_void_p), ('lda', C.c_long), ('amap', RowMap),
+        ('B', C.c_void_p), ('ldb', C.c_long),
+        ('C', C.c_void_p), ('ldc', C.c_long), ('cmap', RowMap),
+        ('bias', C.c_void_p),
+        ('act', C.c_int), ('C2', C.c_void_p), ('ldc2', C.c_long),
+        ('dgelu_in', C.c_void_p), ('ld_dgelu', C.c_long),
+        ('row_scale', C.c_void_p),
+        ('rs_d1', C.c_int), ('rs_m1', C.c_int), ('rs_d2', C.c_int), ('rs_m2', C.c_int),
+        ('R', C.c_void_p), ('ldr', C.c_long), ('rmap', RowMap), ('r_period', C.c_int),
+        ('split_row', C.c_int), ('Csplit', C.c_void_p), ('ldsplit', C.c_long),
+    ]
+
+
+class GemmTnDesc(C.Structure):
+    _fields_ = [
+        ('dtype', C.c_int), ('M', C.c_int), ('N1', C.c_int), ('N2', C.c_int),
+        ('A', C.c_void_p), ('lda', C.c_long), ('amap', RowMap),
+        ('B', C.c_void_p), ('ldb', C.c_long), ('bmap', RowMap),
+        ('C', C.c_void_p), ('ldc', C.c_long), ('accumulate', C.c_int),
+        ('workspace', C.c_void_p), ('ws_bytes', C.c_size_t),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ('dtype', C.c_int), ('mode', C.c_int),
+        ('S', C.c_int), ('L', C.c_int), ('H', C.c_int), ('hd', C.c_int),
+        ('B', C.c_int), ('T', C.c_int), ('P', C.c_int),
+        ('qkv', C.c_void_p), ('ld_qkv', C.c_long),
+        ('out', C.c_void_p), ('ld_out', C.c_long),
+        ('lse', C.c_void_p), ('probs', C.c_void_p), ('scale', C.c_float),
+    ]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ('f', AttnDesc),
+        ('dout', C.c_void_p), ('ld_dout', C.c_long),
+        ('dqkv', C.c_void_p), ('ld_dqkv', C.c_long),
+        ('dqkv_cls', C.c_void_p), ('delta', C.c_void_p),
+    ]
+
+
+vp, ci, cl, cf, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/vtx.h declares.
+SIGNATURES = {
+    'vtx_version': (ci, []),
+    'vtx_last_error_string': (C.c_char_p, []),
+    'vtx_layernorm_fwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, vp, cf, vp, cl, RowMap, vp, vp, vp]),
+    'vtx_layernorm_bwd_workspace': (sz, [ci, ci]),
+    'vtx_layernorm_bwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, vp, vp, vp, vp, cl,
+                               vp, vp, vp, sz, vp]),
+    'vtx_gemm_nt': (ci, [C.POINTER(GemmDesc), vp]),
+    'vtx_gemm_tn_workspace': (sz, [ci, ci, ci]),
+    'vtx_gemm_tn': (ci, [C.POINTER(GemmTnDesc), vp]),
+    'vtx_colsum_workspace': (sz, [ci, ci]),
+    'vtx_colsum': (ci, [ci, ci, ci, vp, cl, RowMap, vp, ci, vp, sz, vp]),
+    'vtx_attn_fwd': (ci, [C.POINTER(AttnDesc), vp]),
+    'vtx_attn_bwd': (ci, [C.POINTER(AttnBwdDesc), vp]),
+    'vtx_cls_mean_fwd': (ci, [ci, ci, ci, ci, vp, cl, vp, vp, cl, cl, vp]),
+    'vtx_space_grad_prep': (ci, [ci, ci, ci, ci, ci, vp, cl, vp, vp, cl, vp]),
+    'vtx_cls_qkv_reduce': (ci, [ci, ci, ci, ci, vp, cl, vp, cl, cl, vp]),
+    'vtx_row_scale_copy': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, ci, ci, ci, ci, vp]),
+    'vtx_reduce_rows': (ci, [ci, ci, ci, ci, vp, cl, cl, cl, cl, vp, cl, cf, ci, vp]),
+    'vtx_cast_transpose': (ci, [ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_cast_from_f32': (ci, [ci, sz, vp, vp, vp]),
+    'vtx_cast_to_f32': (ci, [ci, sz, vp, vp, vp]),
+    'vtx_patch_rows': (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, cl, ci, vp]),
+    'vtx_embed_table': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+    'vtx_hog_table_bytes': (sz, []),
+    'vtx_hog_build_table': (ci, [vp]),
+    'vtx_hog_fwd': (ci, [vp, ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_maskfeat_blend_fwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
+    'vtx_maskfeat_blend_bwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
+    'vtx_maskfeat_loss_fwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, vp]),
+    'vtx_maskfeat_loss_bwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, cf, vp, cl, vp]),
+    'vtx_selftest': (ci, [C.c_char_p, sz]),
+}
+
+_lib = None
+
+
+class VtxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvtx.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise VtxError(
+            f'libvtx.so not found at {LIB_PATH}: build it with '
+            f'`python videotransformer-pytorch_amd/csrc/build.py` (there is no CPU/PyTorch fallback)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VtxError(f'libvtx.so does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().vtx_last_error_string()
+        raise VtxError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -1,0 +1,571 @@
+"""torch.autograd.Function wrappers: one per reference sub-module forward, each
+running its whole forward / backward as a short chain of libvtx kernels.
+
+The residual stream x is [B, 1 + P*T, D] in the compute dtype (float32 = exact
+path, bfloat16 = MFMA bf16 path), token index = 1 + p*T + t (reference
+video_transformer.py:228,236).  Parameters stay float32; their compute-dtype
+copies (and the transposes used by the input-gradient GEMMs) are staged by
+``weights()`` and cached per parameter version.
+"""
+import torch
+
+from . import ops
+from ._lib import IDENT, ATTN_CONTIG, ATTN_SPACE
+
+_wcache = {}
+
+
+def weights(p, dtype, need_t=None):
+    """(W, W^T) copies of Linear weight ``p`` [out,in] in ``dtype``; cached until p changes."""
+    if need_t is None:
+        need_t = torch.is_grad_enabled()
+    key = (id(p), dtype)
+    hit = _wcache.get(key)
+    ver = (p._version, p.data_ptr())
+    if hit is not None and hit[0] == ver and (hit[2] is not None or not need_t):
+        return hit[1], hit[2]
+    w2d = p.detach().reshape(p.shape[0], -1)
+    wc, wt = ops.cast_transpose(w2d, dtype, want_c=True, want_t=need_t)
+    _wcache[key] = (ver, wc, wt)
+    return wc, wt
+
+
+def clear_weight_cache():
+    _wcache.clear()
+
+
+def _empty(shape, like, dtype=None):
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
+
+
+def _chk(x):
+    ops.need_cuda(x)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x
+
+
+# ---------------------------------------------------------------------------------
+class TimeAttnFn(torch.autograd.Function):
+    """DividedTemporalAttentionWithPreNorm.forward, use_cls_token=False
+    (reference transformer.py:234-282)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec):
+        x = _chk(x)
+        B, N1, D = x.shape
+        N = N1 - 1
+        M = B * N
+        hd = D // heads
+        tm = ops.tokmap(N)
+        dtp = x.dtype
+        xn = _empty((M, D), x)
+        mean = _empty((M,), x, torch.float32)
+        rstd = _empty((M,), x, torch.float32)
+        ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        wq, _ = weights(qkv_w, dtp)
+        qkv = _empty((M, 3 * D), x)
+        ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
+        o = _empty((M, D), x)
+        S = M // T
+        lse = _empty((S * heads * T,), x, torch.float32)
+        scale = hd ** -0.5
+        ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, T, heads, hd, scale)
+        wp, _ = weights(proj_w, dtp)
+        a = _empty((M, D), x)
+        ops.gemm_nt(o, wp, a, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(T, 1, 1, 0))
+        wt, _ = weights(tfc_w, dtp)
+        out = torch.empty_like(x)
+        ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=x, rmap=tm)
+        ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
+        ctx.save_for_backward(x, ln_w, qkv_w, proj_w, tfc_w, mean, rstd, xn, qkv, o, lse, a,
+                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.cfg = (T, heads, scale_vec is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, qkv_w, proj_w, tfc_w, mean, rstd, xn, qkv, o, lse, a, sv = ctx.saved_tensors
+        T, heads, has_scale = ctx.cfg
+        sv = sv if has_scale else None
+        dout = _chk(dout)
+        B, N1, D = x.shape
+        N = N1 - 1
+        M = B * N
+        hd = D // heads
+        S = M // T
+        tm = ops.tokmap(N)
+        dtp = x.dtype
+        # temporal_fc
+        d_tfc_w = ops.gemm_tn(dout, a, M, D, D, amap=tm)
+        d_tfc_b = ops.colsum(dout, M, D, amap=tm)
+        _, wtT = weights(tfc_w, dtp, True)
+        da = _empty((M, D), x)
+        ops.gemm_nt(dout, wtT, da, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
+        # proj
+        d_proj_w = ops.gemm_tn(da, o, M, D, D)
+        d_proj_b = ops.colsum(da, M, D)
+        _, wpT = weights(proj_w, dtp, True)
+        do = _empty((M, D), x)
+        ops.gemm_nt(da, wpT, do, M, D, D)
+        # attention core
+        dqkv = _empty((M, 3 * D), x)
+        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, T, heads, hd, hd ** -0.5)
+        d_qkv_w = ops.gemm_tn(dqkv, xn, M, 3 * D, D)
+        d_qkv_b = ops.colsum(dqkv, M, 3 * D)
+        _, wqT = weights(qkv_w, dtp, True)
+        dxn = _empty((M, D), x)
+        ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
+        # LayerNorm + residual
+        dx = torch.empty_like(x)
+        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(dxn, D, IDENT, x, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None)
+
+
+class SpaceAttnFn(torch.autograd.Function):
+    """DividedSpatialAttentionWithPreNorm.forward, use_cls_token=True
+    (reference transformer.py:336-382).  LayerNorm and the qkv / proj Linears are
+    row-wise, so they run once over the natural token order (the cls row once per
+    clip instead of once per frame); only the attention kernel regroups rows."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, T, heads, scale_vec, want_probs):
+        x = _chk(x)
+        B, N1, D = x.shape
+        N = N1 - 1
+        P = N // T
+        M1 = B * N1
+        hd = D // heads
+        dtp = x.dtype
+        xn = _empty((M1, D), x)
+        mean = _empty((M1,), x, torch.float32)
+        rstd = _empty((M1,), x, torch.float32)
+        ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        wq, _ = weights(qkv_w, dtp)
+        qkv = _empty((M1, 3 * D), x)
+        ops.gemm_nt(xn, wq, qkv, M1, 3 * D, D, bias=qkv_b)
+        Mo = B * N + B * T
+        o = _empty((Mo, D), x)
+        S, L = B * T, P + 1
+        lse = _empty((S * heads * L,), x, torch.float32)
+        probs = _empty((S, heads, L, L), x, torch.float32) if want_probs else None
+        ops.attn_fwd(qkv, o, lse, ATTN_SPACE, S, L, heads, hd, hd ** -0.5, B, T, P, probs=probs)
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return probs
+        wp, _ = weights(proj_w, dtp)
+        out = torch.empty_like(x)
+        a_cls = _empty((B * T, D), x)
+        tm = ops.tokmap(N)
+        ops.gemm_nt(o, wp, out, Mo, D, D, cmap=tm, bias=proj_b, row_scale=scale_vec, rs=(N, T, T, 1),
+                    R=x, rmap=tm, split_row=B * N, Csplit=a_cls)
+        ops.cls_mean_fwd(a_cls, x, out, B, T, D, N1)
+        ctx.save_for_backward(x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse,
+                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.cfg = (T, heads, scale_vec is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse, sv = ctx.saved_tensors
+        T, heads, has_scale = ctx.cfg
+        sv = sv if has_scale else None
+        dout = _chk(dout)
+        B, N1, D = x.shape
+        N = N1 - 1
+        P = N // T
+        M1 = B * N1
+        Mo = B * N + B * T
+        hd = D // heads
+        dtp = x.dtype
+        da = _empty((Mo, D), x)
+        ops.space_grad_prep(dout, sv, da, B, T, P, D)
+        d_proj_w = ops.gemm_tn(da, o, Mo, D, D)
+        d_proj_b = ops.colsum(da, Mo, D)
+        _, wpT = weights(proj_w, dtp, True)
+        do = _empty((Mo, D), x)
+        ops.gemm_nt(da, wpT, do, Mo, D, D)
+        dqkv = _empty((M1, 3 * D), x)
+        dqkv_cls = _empty((B * T, 3 * D), x)
+        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_SPACE, B * T, P + 1, heads, hd, hd ** -0.5, B, T, P,
+                     dqkv_cls=dqkv_cls)
+        ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, N1)
+        d_qkv_w = ops.gemm_tn(dqkv, xn, M1, 3 * D, D)
+        d_qkv_b = ops.colsum(dqkv, M1, 3 * D)
+        _, wqT = weights(qkv_w, dtp, True)
+        dxn = _empty((M1, D), x)
+        ops.gemm_nt(dqkv, wqT, dxn, M1, D, 3 * D)
+        dx = torch.empty_like(x)
+        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M1, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None)
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """MultiheadAttentionWithPreNorm.forward (reference transformer.py:428-456):
+    x [Bn, L, D] -> x + DropPath(proj(attn(LN(x))))."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, heads, scale_vec, want_probs):
+        x = _chk(x)
+        Bn, L, D = x.shape
+        M = Bn * L
+        hd = D // heads
+        dtp = x.dtype
+        xn = _empty((M, D), x)
+        mean = _empty((M,), x, torch.float32)
+        rstd = _empty((M,), x, torch.float32)
+        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        wq, _ = weights(qkv_w, dtp)
+        qkv = _empty((M, 3 * D), x)
+        ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
+        o = _empty((M, D), x)
+        lse = _empty((Bn * heads * L,), x, torch.float32)
+        probs = _empty((Bn, heads, L, L), x, torch.float32) if want_probs else None
+        ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, Bn, L, heads, hd, hd ** -0.5, probs=probs)
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return probs
+        wp, _ = weights(proj_w, dtp)
+        out = torch.empty_like(x)
+        ops.gemm_nt(o, wp, out, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(L, 1, 1, 0), R=x)
+        ctx.save_for_backward(x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse,
+                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.cfg = (heads, scale_vec is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse, sv = ctx.saved_tensors
+        heads, has_scale = ctx.cfg
+        dout = _chk(dout)
+        Bn, L, D = x.shape
+        M = Bn * L
+        hd = D // heads
+        dtp = x.dtype
+        if has_scale:
+            da = _empty((M, D), x)
+            ops.row_scale_copy(dout, da, M, D, s=sv, rs=(L, 1, 1, 0))
+        else:
+            da = dout
+        d_proj_w = ops.gemm_tn(da, o, M, D, D)
+        d_proj_b = ops.colsum(da, M, D)
+        _, wpT = weights(proj_w, dtp, True)
+        do = _empty((M, D), x)
+        ops.gemm_nt(da, wpT, do, M, D, D)
+        dqkv = _empty((M, 3 * D), x)
+        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, Bn, L, heads, hd, hd ** -0.5)
+        d_qkv_w = ops.gemm_tn(dqkv, xn, M, 3 * D, D)
+        d_qkv_b = ops.colsum(dqkv, M, 3 * D)
+        _, wqT = weights(qkv_w, dtp, True)
+        dxn = _empty((M, D), x)
+        ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
+        dx = torch.empty_like(x)
+        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None)
+
+
+class FFNFn(torch.autograd.Function):
+    """FFNWithPreNorm.forward with num_layers == 2 (reference transformer.py:516-523)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale_vec):
+        x = _chk(x)
+        D = x.shape[-1]
+        M = x.numel() // D
+        rows_per = M // x.shape[0]
+        Hd = w1.shape[0]
+        dtp = x.dtype
+        xn = _empty((M, D), x)
+        mean = _empty((M,), x, torch.float32)
+        rstd = _empty((M,), x, torch.float32)
+        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        w1c, _ = weights(w1, dtp)
+        h = _empty((M, Hd), x)
+        g = _empty((M, Hd), x)
+        ops.gemm_nt(xn, w1c, g, M, Hd, D, bias=b1, act=1, C2=h)
+        w2c, _ = weights(w2, dtp)
+        out = torch.empty_like(x)
+        ops.gemm_nt(g, w2c, out, M, D, Hd, bias=b2, row_scale=scale_vec, rs=(rows_per, 1, 1, 0), R=x)
+        ctx.save_for_backward(x, ln_w, w1, w2, mean, rstd, xn, h, g,
+                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.cfg = (rows_per, scale_vec is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, w1, w2, mean, rstd, xn, h, g, sv = ctx.saved_tensors
+        rows_per, has_scale = ctx.cfg
+        dout = _chk(dout)
+        D = x.shape[-1]
+        M = x.numel() // D
+        Hd = w1.shape[0]
+        dtp = x.dtype
+        if has_scale:
+            dz = _empty((M, D), x)
+            ops.row_scale_copy(dout, dz, M, D, s=sv, rs=(rows_per, 1, 1, 0))
+        else:
+            dz = dout
+        d_w2 = ops.gemm_tn(dz, g, M, D, Hd)
+        d_b2 = ops.colsum(dz, M, D)
+        _, w2T = weights(w2, dtp, True)
+        dh = _empty((M, Hd), x)
+        ops.gemm_nt(dz, w2T, dh, M, Hd, D, dgelu_in=h)
+        d_w1 = ops.gemm_tn(dh, xn, M, Hd, D)
+        d_b1 = ops.colsum(dh, M, Hd)
+        _, w1T = weights(w1, dtp, True)
+        dxn = _empty((M, D), x)
+        ops.gemm_nt(dh, w1T, dxn, M, D, Hd)
+        dx = torch.empty_like(x)
+        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None)
+
+
+class TokensFn(torch.autograd.Function):
+    """PatchEmbed + prepare_tokens fused (reference transformer.py:138-151 and
+    video_transformer.py:193-240 / :455-502, use_cls_token_temporal=False):
+    clip [B,T,C,H,W] fp32 -> residual stream.
+
+    layout 'pt': [B, 1+P*T', D], token 1+p*T'+t'  (divided / joint attention)
+    layout 'tp': [(B T'), 1+P, D]                 (space_only, ViViT fact_encoder)"""
+
+    @staticmethod
+    def forward(ctx, clip, conv_w, conv_b, cls_token, pos_embed, time_embed, dtype, layout):
+        ops.need_cuda(clip, conv_w)
+        B, T, Cc, H, W = clip.shape
+        D = conv_w.shape[0]
+        ps = conv_w.shape[-1]
+        ts = conv_w.shape[2] if conv_w.ndim == 5 else 1
+        Tq = T // ts
+        P = (H // ps) * (W // ps)
+        K = Cc * ts * ps * ps
+        wc, _ = weights(conv_w, dtype, False)
+        if layout == 'pt':
+            rows = ops.patch_rows(clip, dtype, ps, ts, frame_major=False)        # [(b p t), K]
+            N = P * Tq
+            E, cls_row = ops.embed_table(dtype, P, Tq, D, conv_b, pos_embed.reshape(-1, D),
+                                         None if time_embed is None else time_embed.reshape(-1, D),
+                                         cls_token.reshape(-1))
+            x = torch.empty(B, 1 + N, D, dtype=dtype, device=clip.device)
+            ops.gemm_nt(rows, wc, x, B * N, D, K, cmap=ops.tokmap(N), R=E, r_period=N)
+            nseq, per = B, N
+        else:
+            rows = ops.patch_rows(clip, dtype, ps, ts, frame_major=True)         # [(b t p), K]
+            E, cls_row = ops.embed_table(dtype, P, 1, D, conv_b, pos_embed.reshape(-1, D), None,
+                                         cls_token.reshape(-1))
+            x = torch.empty(B * Tq, 1 + P, D, dtype=dtype, device=clip.device)
+            ops.gemm_nt(rows, wc, x, B * Tq * P, D, K, cmap=ops.tokmap(P), R=E, r_period=P)
+            nseq, per = B * Tq, P
+        # cls rows: every sequence's row 0 = cls_token + pos_embed[0]
+        ops.row_scale_copy(cls_row, x, nseq, D, smap=ops.rowmap(1, -1, 0), dmap=ops.clsmap(per))
+        ctx.save_for_backward(rows)
+        ctx.cfg = (B, Tq, P, D, K, layout, conv_w.shape, pos_embed.shape,
+                   None if time_embed is None else time_embed.shape, cls_token.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (rows,) = ctx.saved_tensors
+        B, Tq, P, D, K, layout, w_shape, pos_shape, time_shape, cls_shape = ctx.cfg
+        dx = _chk(dx)
+        if layout == 'pt':
+            N, nseq = P * Tq, B
+        else:
+            N, nseq = P, B * Tq
+        d_w = ops.gemm_tn(dx, rows, nseq * N, D, K, amap=ops.tokmap(N)).reshape(w_shape)
+        # dE[n,:] = sum over sequences of dx[s, 1+n, :]
+        dE = ops.reduce_rows(dx, N, nseq, D, D, 1, 1 + N, 1)
+        d_b = ops.reduce_rows(dE, 1, N, D, D, 0, 1, 0).reshape(D)
+        d_cls = ops.reduce_rows(dx, 1, nseq, D, D, 0, 1 + N, 0)                   # [1, D]
+        d_pos = torch.empty(1 + P, D, dtype=torch.float32, device=dx.device)
+        d_pos[0:1].copy_(d_cls)
+        d_time = None
+        if layout == 'pt':
+            ops.reduce_rows(dE, P, Tq, D, D, 0, 1, Tq, out=d_pos[1:])
+            if time_shape is not None:
+                d_time = ops.reduce_rows(dE, Tq, P, D, D, 0, Tq, 1).reshape(time_shape)
+        else:
+            d_pos[1:].copy_(dE)
+        return (None, d_w, d_b, d_cls.reshape(cls_shape), d_pos.reshape(pos_shape), d_time, None, None)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed.forward alone (reference transformer.py:138-151): [B,T,C,H,W] ->
+    [(B T'), P, D] = conv projection + bias, reference row order."""
+
+    @staticmethod
+    def forward(ctx, clip, conv_w, conv_b, dtype):
+        ops.need_cuda(clip, conv_w)
+        B, T, Cc, H, W = clip.shape
+        D = conv_w.shape[0]
+        ps = conv_w.shape[-1]
+        ts = conv_w.shape[2] if conv_w.ndim == 5 else 1
+        P = (H // ps) * (W // ps)
+        K = Cc * ts * ps * ps
+        rows = ops.patch_rows(clip, dtype, ps, ts, frame_major=True)
+        wc, _ = weights(conv_w, dtype, False)
+        M = rows.shape[0]
+        y = torch.empty(M, D, dtype=dtype, device=clip.device)
+        ops.gemm_nt(rows, wc, y, M, D, K, bias=conv_b)
+        ctx.save_for_backward(rows)
+        ctx.cfg = (M, D, K, conv_w.shape)
+        return y.reshape(B * (T // ts), P, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        M, D, K, w_shape = ctx.cfg
+        dy = _chk(dy).reshape(M, D)
+        d_w = ops.gemm_tn(dy, rows, M, D, K).reshape(w_shape)
+        d_b = ops.colsum(dy, M, D)
+        return None, d_w, d_b, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of x [.., D]; ``cls_only`` normalises only row 0
+    of every [1+N, D] sequence and returns [B, D] (final norm + x[:, 0],
+    reference video_transformer.py:251-254 / :527-530)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, cls_only):
+        x = _chk(x)
+        D = x.shape[-1]
+        if cls_only:
+            B, N1, _ = x.shape
+            rows, xmap = B, ops.clsmap(N1 - 1)
+            y = _empty((B, D), x)
+        else:
+            rows, xmap = x.numel() // D, IDENT
+            y = torch.empty_like(x)
+        mean = _empty((rows,), x, torch.float32)
+        rstd = _empty((rows,), x, torch.float32)
+        ops.layernorm_fwd(x, rows, D, D, xmap, w, b, eps, y, D, IDENT, mean, rstd)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.cfg = (rows, cls_only)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        rows, cls_only = ctx.cfg
+        dy = _chk(dy)
+        D = x.shape[-1]
+        xmap = ops.clsmap(x.shape[1] - 1) if cls_only else IDENT
+        dx = torch.zeros_like(x) if cls_only else torch.empty_like(x)
+        d_w = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(dy, D, IDENT, x, D, xmap, rows, D, mean, rstd, w, None, dx, D, d_w, d_b)
+        return dx, d_w, d_b, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b on [M, K] rows (decoder_pred / classification head)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _chk(x)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        wc, _ = weights(w, x.dtype)
+        y = _empty(tuple(x.shape[:-1]) + (N,), x)
+        ops.gemm_nt(x, wc, y, M, N, K, bias=b)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        d_w = ops.gemm_tn(dy, x, M, N, K)
+        d_b = ops.colsum(dy, M, N) if ctx.has_bias else None
+        _, wT = weights(w, x.dtype, True)
+        dx = torch.empty_like(x)
+        ops.gemm_nt(dy, wT, dx, M, K, N)
+        return dx, d_w, d_b
+
+
+class CastFn(torch.autograd.Function):
+    """dtype boundary of the path: compute dtype <-> float32."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        if x.dtype == dtype:
+            return x
+        return ops.cast_to_f32(x) if dtype == torch.float32 else ops.cast_from_f32(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy.dtype == ctx.src:
+            return dy, None
+        dy = _chk(dy)
+        return (ops.cast_to_f32(dy) if ctx.src == torch.float32 else ops.cast_from_f32(dy, ctx.src)), None
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v on qkv [Bn, L, 3D] (reference transformer.py:167-174).
+    Returns (ctx [Bn, L, D], probs fp32 [Bn, H, L, L] or None)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, want_probs):
+        qkv = _chk(qkv)
+        Bn, L, D3 = qkv.shape
+        D = D3 // 3
+        hd = D // heads
+        o = _empty((Bn, L, D), qkv)
+        lse = _empty((Bn * heads * L,), qkv, torch.float32)
+        probs = _empty((Bn, heads, L, L), qkv, torch.float32) if want_probs else None
+        ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, Bn, L, heads, hd, hd ** -0.5, probs=probs)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.heads = heads
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return o, probs
+        return o, None
+
+    @staticmethod
+    def backward(ctx, do, _dprobs):
+        qkv, o, lse = ctx.saved_tensors
+        heads = ctx.heads
+        do = _chk(do)
+        Bn, L, D3 = qkv.shape
+        hd = D3 // 3 // heads
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, Bn, L, heads, hd, hd ** -0.5)
+        return dqkv, None, None
+
+
+class RowScaleFn(torch.autograd.Function):
+    """x * s[row // rows_per] (standalone DropPath, reference transformer.py:34-42)."""
+
+    @staticmethod
+    def forward(ctx, x, s, rows_per):
+        x = _chk(x)
+        D = x.shape[-1]
+        y = torch.empty_like(x)
+        ops.row_scale_copy(x, y, x.numel() // D, D, s=s, rs=(rows_per, 1, 1, 0))
+        ctx.save_for_backward(s)
+        ctx.rows_per = rows_per
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        dy = _chk(dy)
+        D = dy.shape[-1]
+        dx = torch.empty_like(dy)
+        ops.row_scale_copy(dy, dx, dy.numel() // D, D, s=s, rs=(ctx.rows_per, 1, 1, 0))
+        return dx, None, None

@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C ABI (one Python function per libvtx entry point).
+
+PyTorch is used here only for device memory (``torch.empty``), the current HIP
+stream and dtype bookkeeping; every FLOP on the path is issued by libvtx.so.
+All tensors must be CUDA (HIP) tensors; CPU tensors raise -- there is no fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import RowMap, IDENT, GemmDesc, GemmTnDesc, AttnDesc, AttnBwdDesc, call
+
+_DT = {torch.float32: _lib.VTX_F32, torch.bfloat16: _lib.VTX_BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f'vtx: unsupported activation dtype {t.dtype} (float32 or bfloat16)')
+
+
+def need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('vtx: the HIP path needs CUDA/HIP tensors (no CPU fallback); '
+                               f'got a tensor on {t.device}')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rowmap(grp=0, skip=0, base=0):
+    return RowMap(int(grp), int(skip), int(base))
+
+
+def tokmap(n_tokens):
+    """logical token row (clip-major, no cls) -> physical row of a [B, 1+N, D] tensor."""
+    return RowMap(int(n_tokens), 1, 1)
+
+
+def clsmap(n_tokens):
+    """logical row b -> physical row b*(1+N): the cls row of every clip."""
+    return RowMap(1, int(n_tokens), 0)
+
+
+def _f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError('vtx: parameter tensors must be float32')
+    return t
+
+
+# ------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, rows, D, ldx, xmap, gamma, beta, eps, y, ldy, ymap=IDENT, mean=None, rstd=None):
+    need_cuda(x, y, gamma, beta)
+    call('vtx_layernorm_fwd', dt(x), rows, D, ptr(x), ldx, xmap, ptr(_f32(gamma)), ptr(_f32(beta)), float(eps),
+         ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
+
+
+def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dres, dx, lddx, dgamma, dbeta):
+    need_cuda(dy, x, dx)
+    ws_bytes = _lib.load().vtx_layernorm_bwd_workspace(rows, D)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    call('vtx_layernorm_bwd', dt(x), rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd),
+         ptr(gamma), ptr(dres), ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, stream())
+
+
+# ----------------------------------------------------------------------- GEMM
+def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=IDENT, bias=None, act=0,
+            C2=None, dgelu_in=None, row_scale=None, rs=(1, 0, 1, 0), R=None, ldr=None, rmap=IDENT,
+            r_period=0, split_row=0, Csplit=None):
+    """C = epilogue(A[M,K] @ B[N,K]^T); see vtx_gemm_nt in include/vtx.h."""
+    need_cuda(A, B, Cout)
+    if A.dtype != B.dtype or A.dtype != Cout.dtype:
+        raise TypeError(f'gemm_nt: dtype mismatch {A.dtype} {B.dtype} {Cout.dtype}')
+    d = GemmDesc()
+    d.dtype = dt(A); d.M, d.N, d.K = int(M), int(N), int(K)
+    d.A = ptr(A); d.lda = K if lda is None else lda; d.amap = amap
+    d.B = ptr(B); d.ldb = K if ldb is None else ldb
+    d.C = ptr(Cout); d.ldc = N if ldc is None else ldc; d.cmap = cmap
+    d.bias = ptr(_f32(bias)); d.act = act
+    d.C2 = ptr(C2); d.ldc2 = N
+    d.dgelu_in = ptr(dgelu_in); d.ld_dgelu = N
+    d.row_scale = ptr(_f32(row_scale)); d.rs_d1, d.rs_m1, d.rs_d2, d.rs_m2 = [int(v) for v in rs]
+    d.R = ptr(R); d.ldr = (N if ldr is None else ldr); d.rmap = rmap; d.r_period = int(r_period)
+    d.split_row = int(split_row); d.Csplit = ptr(Csplit); d.ldsplit = N
+    call('vtx_gemm_nt', C.byref(d), stream())
+
+
+def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDENT, accumulate=False):
+    """out[N1,N2] (fp32) (+)= sum_m A[m,:N1]^T B[m,:N2]."""
+    need_cuda(A, B)
+    if out is None:
+        out = torch.empty(N1, N2, dtype=torch.float32, device=A.device)
+    ws_bytes = _lib.load().vtx_gemm_tn_workspace(M, N1, N2)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
+    d = GemmTnDesc()
+    d.dtype = dt(A); d.M, d.N1, d.N2 = int(M), int(N1), int(N2)
+    d.A = ptr(A); d.lda = N1 if lda is None else lda; d.amap = amap
+    d.B = ptr(B); d.ldb = N2 if ldb is None else ldb; d.bmap = bmap
+    d.C = ptr(out); d.ldc = N2; d.accumulate = int(bool(accumulate))
+    d.workspace = ptr(ws); d.ws_bytes = ws_bytes
+    call('vtx_gemm_tn', C.byref(d), stream())
+    return out
+
+
+def colsum(A, M, N, lda=None, amap=IDENT, out=None, accumulate=False):
+    need_cuda(A)
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=A.device)
+    ws_bytes = _lib.load().vtx_colsum_workspace(M, N)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
+    call('vtx_colsum', dt(A), M, N, ptr(A), N if lda is None else lda, amap, ptr(out), int(bool(accumulate)),
+         ptr(ws), ws_bytes, stream())
+    return out
+
+
+# ------------------------------------------------------------------ attention
+def _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B=0, T=0, P=0, probs=None):
+    d = AttnDesc()
+    d.dtype = dt(qkv); d.mode = mode
+    d.S, d.L, d.H, d.hd = int(S), int(L), int(H), int(hd)
+    d.B, d.T, d.P = int(B), int(T), int(P)
+    d.qkv = ptr(qkv); d.ld_qkv = 3 * H * hd
+    d.out = ptr(out); d.ld_out = H * hd
+    d.lse = ptr(lse); d.probs = ptr(probs); d.scale = float(scale)
+    return d
+
+
+def attn_fwd(qkv, out, lse, mode, S, L, H, hd, scale, B=0, T=0, P=0, probs=None):
+    need_cuda(qkv, out, lse)
+    d = _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B, T, P, probs)
+    call('vtx_attn_fwd', C.byref(d), stream())
+
+
+def attn_bwd(qkv, out, lse, dout, dqkv, mode, S, L, H, hd, scale, B=0, T=0, P=0, dqkv_cls=None):
+    need_cuda(qkv, out, dout, dqkv)
+    b = AttnBwdDesc()
+    b.f = _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B, T, P)
+    b.dout = ptr(dout); b.ld_dout = H * hd
+    b.dqkv = ptr(dqkv); b.ld_dqkv = 3 * H * hd
+    b.dqkv_cls = ptr(dqkv_cls)
+    delta = torch.empty(S * H * L, dtype=torch.float32, device=qkv.device)
+    b.delta = ptr(delta)
+    call('vtx_attn_bwd', C.byref(b), stream())
+
+
+# ------------------------------------------------------------------- glue ops
+def cls_mean_fwd(a_cls, x, out, B, T, D, rows_per_clip):
+    call('vtx_cls_mean_fwd', dt(x), B, T, D, ptr(a_cls), D, ptr(x), ptr(out), D, rows_per_clip, stream())
+
+
+def space_grad_prep(dout, s, da, B, T, P, D):
+    call('vtx_space_grad_prep', dt(dout), B, T, P, D, ptr(dout), D, ptr(s), ptr(da), D, stream())
+
+
+def cls_qkv_reduce(dqkv_cls, dqkv, B, T, W, rows_per_clip):
+    call('vtx_cls_qkv_reduce', dt(dqkv), B, T, W, ptr(dqkv_cls), W, ptr(dqkv), W, rows_per_clip, stream())
+
+
+def row_scale_copy(src, dst, rows, D, lds=None, smap=IDENT, ldd=None, dmap=IDENT, s=None, rs=(1, 0, 1, 0)):
+    need_cuda(src, dst)
+    call('vtx_row_scale_copy', dt(src), rows, D, ptr(src), D if lds is None else lds, smap, ptr(dst),
+         D if ldd is None else ldd, dmap, ptr(s), int(rs[0]), int(rs[1]), int(rs[2]), int(rs[3]), stream())
+
+
+def reduce_rows(inp, nj, ni, D, ld, base, si, sj, out=None, scale=1.0, accumulate=False):
+    need_cuda(inp)
+    if out is None:
+        out = torch.empty(nj, D, dtype=torch.float32, device=inp.device)
+    call('vtx_reduce_rows', dt(inp), nj, ni, D, ptr(inp), ld, base, si, sj, ptr(out), D, float(scale),
+         int(bool(accumulate)), stream())
+    return out
+
+
+def cast_transpose(W, dtype, want_c=True, want_t=True):
+    """fp32 [R,C] parameter -> (Wc [R,C], WcT [C,R]) in `dtype` (fp32: Wc is W itself)."""
+    need_cuda(W)
+    R, Cc = W.shape
+    W = W.contiguous()
+    code = _DT[dtype]
+    Wc = None
+    if want_c:
+        Wc = W if dtype == torch.float32 else torch.empty(R, Cc, dtype=dtype, device=W.device)
+    WcT = torch.empty(Cc, R, dtype=dtype, device=W.device) if want_t else None
+    wc_arg = None if (Wc is None or Wc is W) else Wc
+    if wc_arg is not None or WcT is not None:
+        call('vtx_cast_transpose', code, R, Cc, ptr(W), ptr(wc_arg), ptr(WcT), stream())
+    return Wc, WcT
+
+
+def cast_from_f32(src, dtype):
+    need_cuda(src)
+    if dtype == torch.float32:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    call('vtx_cast_from_f32', _DT[dtype], src.numel(), ptr(src.contiguous()), ptr(dst), stream())
+    return dst
+
+
+def cast_to_f32(src):
+    need_cuda(src)
+    if src.dtype == torch.float32:
+        return src
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    call('vtx_cast_to_f32', dt(src), src.numel(), ptr(src.contiguous()), ptr(dst), stream())
+    return dst
+
+
+def patch_rows(clip, dtype, ps, ts, frame_major):
+    """[B,T,C,H,W] fp32 -> [B*(T/ts)*P, C*ts*ps*ps] rows in `dtype`."""
+    need_cuda(clip)
+    if clip.dtype != torch.float32:
+        clip = clip.float()
+    clip = clip.contiguous()
+    B, T, Cc, H, W = clip.shape
+    K = Cc * ts * ps * ps
+    rows = torch.empty(B * (T // ts) * (H // ps) * (W // ps), K, dtype=dtype, device=clip.device)
+    call('vtx_patch_rows', _DT[dtype], B, T, Cc, H, W, ps, ts, ptr(clip), ptr(rows), K, int(frame_major), stream())
+    return rows
+
+
+def embed_table(dtype, P, T, D, bias, pos, time_embed, cls, frame_major=False):
+    dev = pos.device
+    E = torch.empty(P * T, D, dtype=dtype, device=dev)
+    cls_row = torch.empty(D, dtype=dtype, device=dev) if cls is not None else None
+    call('vtx_embed_table', _DT[dtype], P, T, D, ptr(bias), ptr(pos), ptr(time_embed), ptr(cls), ptr(E),
+         ptr(cls_row), int(frame_major), stream())
+    return E, cls_row
+
+
+# ------------------------------------------------------------------------ HOG
+_hog_tables = {}
+
+
+def hog_table(device):
+    key = str(device)
+    if key not in _hog_tables:
+        host = torch.empty(256 * 256, dtype=torch.float64)
+        call('vtx_hog_build_table', host.data_ptr())
+        _hog_tables[key] = host.to(device)
+    return _hog_tables[key]
+
+
+def hog_fwd(frames, want_bins=False):
+    """frames uint8 [F,H,W,3] (CUDA) -> float64 [F,H/16,W/16,108] (+ int32 bins [F,3,H,W])."""
+    need_cuda(frames)
+    if frames.dtype != torch.uint8 or frames.ndim != 4 or frames.shape[-1] != 3:
+        raise TypeError('hog_fwd: frames must be uint8 [F,H,W,3]')
+    frames = frames.contiguous()
+    F, H, W, _ = frames.shape
+    out = torch.empty(F, H // 16, W // 16, 108, dtype=torch.float64, device=frames.device)
+    bins = torch.empty(F, 3, H, W, dtype=torch.int32, device=frames.device) if want_bins else None
+    call('vtx_hog_fwd', ptr(frames), F, H, W, ptr(hog_table(frames.device)), ptr(out), ptr(bins), stream())
+    return (out, bins) if want_bins else out
