@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: TimeSformer-B divided_space_time, 8 x 3 x 224 x 224 synthetic clips,
+bf16 HIP path, one training step = forward + cross-entropy + backward (+ gradient
+all-reduce for N > 1) + SGD update, on N GPUs of one node (one process per GPU, RCCL).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames T]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the keys below).  `value` = clips/s over all N GPUs
+with clips already resident in HBM.  `roofline` is for the dominant kernel
+(gemm_nt_bf16_kernel): achieved = algorithmic FLOPs (2*M*N*K per launch) / launch time
+measured with HIP events on the launch stream inside the timed region, against the
+2.5 PFLOP/s dense bf16 MFMA peak.  `cpu_baseline` times the CPU oracle (oracle/, fp32,
+all host cores) on a bounded sample of the same workload -- a reported baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'videotransformer-pytorch_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOPS_FWD_BWD_PER_CLIP = {8: 1.175e12, 16: 2.352e12, 2: 0.2937e12}
+PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='clips per GPU (weak scaling)')
+    ap.add_argument('--frames', type=int, default=8)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='extra instrumented pass: per-kernel-class time')
+    ap.add_argument('--no-optimizer', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, steps=2):
+    """CPU oracle (fp32, torch CPU kernels on every host core), fwd+bwd of the same model on one clip."""
+    from oracle import synth, vt_oracle as O
+    import video_transformer as V
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = synth.synth_state_dict(synth.shapes_of(V.TimeSformer(num_frames=frames)), 0)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = synth.synth_clip(1, frames, seed=1)
+    times = []
+    for i in range(steps + 1):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        torch.manual_seed(i)
+        y = O.timesformer_forward(sd, x, frames, training=True)
+        y.sum().backward()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / steps
+    return {'value': round(1.0 / t, 4), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle/vt_oracle.py TimeSformer-B {frames}x224^2 fp32 train fwd+bwd, batch 1, '
+                      f'{steps} timed steps after 1 warm-up'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    import __graft_entry__ as ge
+    ge.ensure_built()
+    import vtx
+    from vtx import dp, ops
+    import transformer as T
+    import video_transformer as V
+
+    vtx.set_precision(args.precision)
+    torch.manual_seed(0)
+    model = V.TimeSformer(num_frames=args.frames)
+    head = T.ClassificationHead(400, model.embed_dims)
+    with torch.no_grad():                               # temporal_fc is zero-initialised: give it weight
+        for blk in model.transformer_layers.layers:
+            blk.attentions[0].temporal_fc.weight.normal_(0, 0.02)
+    model.to(dev).train()
+    head.to(dev).train()
+    params = list(model.parameters()) + list(head.parameters())
+    dp.broadcast_parameters(model)
+    dp.broadcast_parameters(head)
+    buckets = dp.GradBuckets(params) if world > 1 else None
+    opt = None if args.no_optimizer else torch.optim.SGD(params, lr=1e-4, momentum=0.9, nesterov=True)
+
+    B = args.batch
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    x = torch.randn(B, args.frames, 3, 224, 224, generator=g).to(dev)
+    labels = torch.randint(0, 400, (B,), generator=g).to(dev)
+
+    def step():
+        if buckets is not None:
+            buckets.zero()
+        else:
+            for p in params:
+                p.grad = None
+        logits = head(model(x))
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.profile_start(('gemm_nt',))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss)
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        classes = ('gemm_nt', 'gemm_tn', 'attn_fwd', 'attn_bwd', 'ln_fwd', 'ln_bwd', 'colsum')
+        ops.profile_start(classes)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        tot = (time.perf_counter() - t1) / 3 * 1e3
+        pr = ops.profile_stop()
+        breakdown = {c: {'launches_per_step': n // 3, 'ms_per_step': round(ms / 3, 3),
+                         'work_per_s': round(w / (ms * 1e-3), 3) if ms else None} for c, (n, ms, w) in pr.items()}
+        breakdown['step_ms_instrumented'] = round(tot, 3)
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        n, ms, flops = prof['gemm_nt']
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            'metric': 'clips/sec TimeSformer-B divided_space_time %dx3x224x224 fwd+bwd (whole job)' % args.frames,
+            'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'TimeSformer-B divided_space_time, %d frames x 3x224x224, %s, fwd+CE+bwd%s, '
+                                   'random-init weights' % (args.frames, args.precision,
+                                                            '' if args.no_optimizer else '+SGD(nesterov)'),
+                       'clips_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'grad_exchange': 'RCCL all-reduce, per-layer fp32 buckets overlapped with backward'
+                       if world > 1 else 'none'},
+            'clips_per_sec_per_gpu': round(value / world, 3),
+            'model_tflops_per_gpu': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12, 2),
+            'mfma_frac_whole_step': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12 / PEAK_BF16, 4),
+            'final_loss': round(final_loss, 4),
+            'roofline': {'kernel': 'gemm_nt_bf16_kernel' if args.precision == 'bf16' else 'gemm_nt_f32_kernel',
+                         'bound': 'mfma', 'achieved': round(achieved, 2),
+                         'peak': PEAK_BF16 if args.precision == 'bf16' else 157.3, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / (PEAK_BF16 if args.precision == 'bf16' else 157.3), 4),
+                         'traffic': None, 'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
+                         'flops_per_launch_avg': round(flops / max(n, 1), 0)},
+        }
+        if breakdown is not None:
+            out['breakdown'] = breakdown
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args.frames)
+            except Exception as e:          # the baseline must never take the bench line down
+                out['cpu_baseline'] = {'value': None, 'unit': 'clips/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                       'sample': 'failed: %r' % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

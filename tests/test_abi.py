@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/vtx.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from helpers import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'vtx.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vtx_[a-z0-9_]+)\s*\(', src)))
+
+
+def _lib_path():
+    import __graft_entry__ as ge
+    ge.ensure_built()
+    return os.path.join(ROOT, 'videotransformer-pytorch_amd', 'libvtx.so')
+
+
+def test_header_declares_expected_surface():
+    names = _declared()
+    for must in ['vtx_layernorm_fwd', 'vtx_layernorm_bwd', 'vtx_gemm_nt', 'vtx_gemm_tn', 'vtx_attn_fwd', 'vtx_attn_bwd',
+                 'vtx_patch_rows', 'vtx_cls_mean_fwd', 'vtx_hog_fwd', 'vtx_maskfeat_blend_fwd', 'vtx_maskfeat_loss_fwd',
+                 'vtx_maskfeat_loss_bwd', 'vtx_version', 'vtx_last_error_string']:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib_path())
+    for name in _declared():
+        assert hasattr(lib, name), f'libvtx.so does not export {name}'
+    lib.vtx_version.restype = ctypes.c_int
+    assert lib.vtx_version() >= 100
+
+
+def test_python_binding_covers_header():
+    from vtx import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    _lib.load()
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    """Argument validation happens before any launch: callable on a GPU-less host."""
+    from vtx import _lib
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    d.dtype, d.M, d.N, d.K = 1, 16, 12, 64                      # N not a multiple of 8
+    assert lib.vtx_gemm_nt(ctypes.byref(d), None) == -1
+    assert b'multiples of 8' in lib.vtx_last_error_string()
+    assert lib.vtx_hog_fwd(None, 1, 224, 224, None, None, None, None) == -1
+    a = _lib.AttnDesc()
+    a.S, a.L, a.H, a.hd = 1, 8, 2, 48                            # unsupported head dim
+    assert lib.vtx_attn_fwd(ctypes.byref(a), None) == -1

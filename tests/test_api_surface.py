@@ -1,0 +1,107 @@
+"""Drop-in API surface: class names, constructor kwargs, state_dict keys, error behaviour."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import gold_keys
+
+
+def test_state_dict_contract_timesformer_b():
+    import video_transformer as V
+    m = V.TimeSformer(num_frames=8)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == gold_keys()['timesformer_b_t8']
+    assert len(got) == 247
+    assert m.embed_dims == 768 and m.num_frames == 8 and m.use_cls_token_temporal is False
+    assert m.no_weight_decay_keywords() == {'pos_embed', 'cls_token', 'mask_token'}
+
+
+def test_state_dict_contract_vivit_b():
+    import video_transformer as V
+    m = V.ViViT(num_frames=16)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == gold_keys()['vivit_b_t16']
+    assert m.num_frames == 8 and m.tube_size == 2
+
+
+def test_constructor_signatures_match_reference():
+    import transformer as T
+    import video_transformer as V
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(V.TimeSformer.__init__)[1:] == [
+        'num_frames', 'img_size', 'patch_size', 'pretrain_pth', 'weights_from', 'embed_dims', 'num_heads',
+        'num_transformer_layers', 'in_channels', 'conv_type', 'dropout_p', 'attention_type', 'norm_layer',
+        'copy_strategy', 'use_learnable_pos_emb', 'return_cls_token', 'kwargs']
+    assert sig(T.PatchEmbed.__init__)[1:] == ['img_size', 'patch_size', 'tube_size', 'in_channels', 'embed_dims', 'conv_type']
+    assert sig(T.Attention.__init__)[1:] == ['dim', 'num_heads', 'qkv_bias', 'qk_scale', 'attn_drop', 'proj_drop']
+    assert sig(T.TransformerContainer.__init__)[1:] == [
+        'num_transformer_layers', 'embed_dims', 'num_heads', 'num_frames', 'hidden_channels', 'operator_order',
+        'drop_path_rate', 'norm_layer', 'act_layer', 'num_layers']
+    assert sig(T.DividedSpatialAttentionWithPreNorm.forward)[1:] == ['query', 'key', 'value', 'residual', 'return_attention', 'kwargs']
+    assert sig(V.MaskFeat.forward)[1:] == ['x', 'target_x', 'mask', 'cube_marker', 'visualize']
+
+
+def test_layer_drop_dict_is_consumed_like_the_reference():
+    import transformer as T
+    d = dict(type=T.DropPath, dropout_p=0.1)
+    T.FFNWithPreNorm(embed_dims=64, hidden_channels=256, layer_drop=d)
+    assert d == {}                                   # both keys popped (reference transformer.py:510-511)
+
+
+def test_cpu_tensors_fail_loudly():
+    import video_transformer as V
+    m = V.TimeSformer(num_frames=2, img_size=32, embed_dims=128, num_heads=2, num_transformer_layers=1)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.randn(1, 2, 3, 32, 32))
+
+
+def test_unknown_types_raise_typeerror():
+    import transformer as T
+    with pytest.raises(TypeError):
+        T.PatchEmbed(32, 16, conv_type='Conv1d')
+    with pytest.raises(TypeError):
+        T.BasicTransformerBlock(64, 1, 2, 256, ['nope'])
+
+
+def test_droppath_draws_match_reference_stream():
+    """scale_vector draws torch.rand((rows,1,1)) from the CPU default generator, nothing when p == 0 / eval."""
+    import transformer as T
+    dp = T.DropPath(0.1)
+    dp.train()
+    torch.manual_seed(0)
+    s = dp.scale_vector(6, 3, torch.device('cpu'))
+    torch.manual_seed(0)
+    u = torch.rand((6, 1, 1))
+    want = torch.floor(0.9 + u).reshape(6) / 0.9
+    assert torch.allclose(s, want)
+    torch.manual_seed(1)
+    assert T.DropPath(0.0).train().scale_vector(6, 3, torch.device('cpu')) is None
+    assert dp.eval().scale_vector(6, 3, torch.device('cpu')) is None
+    torch.manual_seed(1)
+    first = torch.rand(1)
+    torch.manual_seed(1)
+    T.DropPath(0.0).train().scale_vector(6, 3, torch.device('cpu'))
+    assert torch.equal(first, torch.rand(1))         # no draw consumed
+
+
+def test_rowmaps():
+    from vtx import ops
+
+    def phys(m, r):
+        return m.base + r + ((r // m.grp) * m.skip if m.grp > 0 else 0)
+    N = 12
+    tm = ops.tokmap(N)
+    assert [phys(tm, r) for r in (0, 11, 12, 25)] == [1, 12, 14, 28]       # b*(N+1) + 1 + n
+    cm = ops.clsmap(N)
+    assert [phys(cm, r) for r in (0, 1, 2)] == [0, 13, 26]
+    bm = ops.rowmap(1, -1, 0)
+    assert [phys(bm, r) for r in (0, 5)] == [0, 0]                         # broadcast row 0
+
+
+def test_sincos_table_matches_formula():
+    import transformer as T
+    t = T.get_sine_cosine_pos_emb(5, 8)
+    assert t.shape == (1, 5, 8)
+    pos, j = 3, 5
+    assert abs(t[0, pos, j].item() - np.cos(pos / 10000 ** (2 * (j // 2) / 8))) < 1e-6

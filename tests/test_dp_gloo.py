@@ -1,0 +1,63 @@
+"""N>1 path on CPU: world_size-2 gloo run of the gradient-bucket exchange (vtx/dp.py)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vtx import dp
+    torch.manual_seed(100 + rank)                       # different init per rank on purpose
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 8),
+                                torch.nn.LayerNorm(8))
+    dp.broadcast_parameters(model)
+    ref = [p.detach().clone() for p in model.parameters()]
+    buckets = dp.GradBuckets(model.parameters(), bucket_bytes=1024)     # forces several buckets
+    assert len(buckets.buckets) >= 2
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(8, 16, generator=g)                              # global batch of 8 "clips"
+    mine = dp.shard_clips(8, rank, world)
+    for step in range(2):
+        buckets.zero()
+        loss = model(data[mine]).pow(2).sum() / 8
+        loss.backward()
+        buckets.finish()
+    got = [p.grad.clone() for p in model.parameters()]
+    # single-process reference on the full batch with rank 0's (broadcast) weights
+    m2 = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 8), torch.nn.LayerNorm(8))
+    for p, r in zip(m2.parameters(), ref):
+        p.data.copy_(r)
+    (m2(data).pow(2).sum() / 8 / world).backward()                      # mean over ranks of per-rank sums
+    err = max((a - b.grad).abs().max().item() for a, b in zip(got, m2.parameters()))
+    same_w = all(torch.equal(a, b) for a, b in zip(ref, [p.detach() for p in model.parameters()]))
+    ret[rank] = (err, same_w, len(buckets.buckets))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    world = 2
+    port = 29500 + (os.getpid() % 1000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        err, same_w, nb = ret[r]
+        assert err < 1e-6, f'rank {r}: averaged gradient mismatch {err}'
+        assert same_w
+
+
+def test_shard_clips_partition():
+    sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
+    from vtx import dp
+    parts = [dp.shard_clips(10, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(10))
+    assert parts[1] == [1, 5, 9]

@@ -1,0 +1,404 @@
+"""Kernel-level parity: every libvtx entry point against a plain fp32/fp64 PyTorch-CPU
+restatement of the same op on seeded inputs (called through the C ABI via vtx.ops).
+
+fp32 path bar: 1e-3 of max|ref| (BASELINE north_star); in practice ~1e-6.
+bf16 path: inputs are rounded to bf16 first, the reference is computed in fp64 from the
+rounded inputs, bar 1e-2 (one bf16 output rounding is 2^-9 = 2e-3 of the element).
+Bit-exact: patch gather (fp32), HOG features and bins.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import check, gold, relerr, report
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """round to the compute dtype and come back to fp64 (what the kernel actually sees)."""
+    return t.to(dtype).double()
+
+
+def dev(t, dtype=None):
+    return (t if dtype is None else t.to(dtype)).to(DEV).contiguous()
+
+
+def phys(m, r):
+    return m.base + r + ((r // m.grp) * m.skip if m.grp > 0 else 0)
+
+
+def test_selftest():
+    import vtx
+    buf = ctypes.create_string_buffer(16384)
+    fails = vtx.load().vtx_selftest(buf, len(buf))
+    report('selftest:\n' + buf.value.decode())
+    assert fails == 0, buf.value.decode()
+
+
+# --------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('D', [128, 768, 1024])
+def test_layernorm_fwd_bwd(dtype, D):
+    from vtx import ops
+    B, N = 3, 37
+    x = rnd(B, 1 + N, D, seed=1) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    dy = rnd(B * N, D, seed=4)
+    dres = rnd(B, 1 + N, D, seed=5)
+    xq = q(x, dtype).requires_grad_(True)
+    gq, bq = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xq[:, 1:], (D,), gq, bq, 1e-5).reshape(B * N, D)
+    ref.backward(q(dy, dtype))
+    dx_ref = xq.grad + q(dres, dtype)
+    dx_ref[:, 0] = 0
+    tm = ops.tokmap(N)
+    xd = dev(x, dtype)
+    y = torch.empty(B * N, D, dtype=dtype, device=DEV)
+    mean = torch.empty(B * N, device=DEV)
+    rstd = torch.empty(B * N, device=DEV)
+    ops.layernorm_fwd(xd, B * N, D, D, tm, dev(gamma), dev(beta), 1e-5, y, D, mean=mean, rstd=rstd)
+    check(f'ln_fwd {dtype} D={D}', y.float().cpu(), ref.detach(), TOL[dtype])
+    check(f'ln_mean {dtype} D={D}', mean.cpu(), xq[:, 1:].detach().mean(-1).reshape(-1), 1e-4)
+    dx = torch.zeros(B, 1 + N, D, dtype=dtype, device=DEV)
+    dg = torch.zeros(D, device=DEV)
+    db = torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dev(dy, dtype), D, ops.IDENT, xd, D, tm, B * N, D, mean, rstd, dev(gamma), dev(dres, dtype), dx, D, dg, db)
+    check(f'ln_bwd dx {dtype} D={D}', dx.float().cpu(), dx_ref, TOL[dtype])
+    check(f'ln_bwd dgamma {dtype} D={D}', dg.cpu(), gq.grad, TOL[dtype])
+    check(f'ln_bwd dbeta {dtype} D={D}', db.cpu(), bq.grad, TOL[dtype])
+
+
+# --------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1568, 2304, 768), (130, 216, 768), (257, 768, 96), (64, 8, 8)])
+def test_gemm_nt_plain(dtype, M, N, K):
+    from vtx import ops
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
+    ref = q(A, dtype) @ q(W, dtype).t() + b.double()
+    C = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, N, K, bias=dev(b))
+    check(f'gemm_nt {dtype} {M}x{N}x{K}', C.float().cpu(), ref, TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gemm_nt_epilogues(dtype):
+    from vtx import ops
+    B, N, T, D, Hd = 2, 24, 4, 128, 256            # N = P*T tokens per clip, P = 6
+    M = B * N
+    tm = ops.tokmap(N)
+    A, W, bias = rnd(M, D, seed=1), rnd(Hd, D, seed=2) * D ** -0.5, rnd(Hd, seed=3)
+    Aq, Wq = q(A, dtype), q(W, dtype)
+    # (1) bias + GELU with pre-activation copy
+    pre = Aq @ Wq.t() + bias.double()
+    C = torch.empty(M, Hd, dtype=dtype, device=DEV)
+    C2 = torch.empty(M, Hd, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, bias=dev(bias), act=1, C2=C2)
+    check(f'gemm gelu {dtype}', C.float().cpu(), torch.nn.functional.gelu(pre), TOL[dtype])
+    check(f'gemm preact {dtype}', C2.float().cpu(), pre, TOL[dtype])
+    # (2) GELU' multiply (FFN backward)
+    h = rnd(M, Hd, seed=4)
+    hq = q(h, dtype).requires_grad_(True)
+    torch.nn.functional.gelu(hq).sum().backward()
+    ref = (Aq @ Wq.t()) * hq.grad
+    ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, dgelu_in=dev(h, dtype))
+    check(f'gemm dgelu {dtype}', C.float().cpu(), ref, TOL[dtype])
+    # (3) A rows through the token map, per-(b,p) row scale, residual + output through the map
+    X = rnd(B, 1 + N, D, seed=5)
+    R = rnd(B, 1 + N, Hd, seed=6)
+    s = (torch.rand(M // T, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7
+    Xq = q(X, dtype)
+    ref = (Xq[:, 1:].reshape(M, D) @ Wq.t() + bias.double()) * s.double().repeat_interleave(T)[:, None]
+    ref = ref.reshape(B, N, Hd) + q(R, dtype)[:, 1:]
+    out = torch.zeros(B, 1 + N, Hd, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(X, dtype), dev(W, dtype), out, M, Hd, D, amap=tm, cmap=tm, bias=dev(bias), row_scale=dev(s),
+                rs=(T, 1, 1, 0), R=dev(R, dtype), rmap=tm)
+    check(f'gemm map+scale+residual {dtype}', out.float().cpu()[:, 1:], ref, TOL[dtype])
+    assert out[:, 0].abs().max().item() == 0, 'cls rows must not be touched'
+    # (4) periodic residual (embedding table)
+    E = rnd(N, Hd, seed=8)
+    ref = (Aq @ Wq.t()).reshape(B, N, Hd) + q(E, dtype)[None]
+    ops.gemm_nt(dev(A, dtype), dev(W, dtype), out, M, Hd, D, cmap=tm, R=dev(E, dtype), r_period=N)
+    check(f'gemm periodic residual {dtype}', out.float().cpu()[:, 1:], ref, TOL[dtype])
+    # (5) split output region + spatial scale indexing (tokens (b, p*T+t) -> s[b*T+t]; tail rows -> s[row])
+    Mo = M + B * T
+    A2 = rnd(Mo, D, seed=9)
+    s2 = (torch.rand(B * T, generator=torch.Generator().manual_seed(10)) > 0.3).float() / 0.7
+    full = q(A2, dtype) @ Wq.t() + bias.double()
+    n_idx = torch.arange(M)
+    tok_scale = s2.double()[(n_idx // N) * T + (n_idx % T)]
+    ref_tok = (full[:M] * tok_scale[:, None]).reshape(B, N, Hd) + q(R, dtype)[:, 1:]
+    ref_cls = full[M:] * s2.double()[:, None]
+    out.zero_()
+    a_cls = torch.empty(B * T, Hd, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(A2, dtype), dev(W, dtype), out, Mo, Hd, D, cmap=tm, bias=dev(bias), row_scale=dev(s2),
+                rs=(N, T, T, 1), R=dev(R, dtype), rmap=tm, split_row=M, Csplit=a_cls)
+    check(f'gemm split tokens {dtype}', out.float().cpu()[:, 1:], ref_tok, TOL[dtype])
+    check(f'gemm split cls rows {dtype}', a_cls.float().cpu(), ref_cls, TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304)])
+def test_gemm_tn(dtype, M, N1, N2, monkeypatch):
+    from vtx import ops
+    A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
+    ref = q(A, dtype).t() @ q(Bm, dtype)
+    for safe in (['0', '1'] if dtype == torch.bfloat16 else ['0']):
+        monkeypatch.setenv('VTX_TN_SAFE', safe)
+        C = ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2)
+        check(f'gemm_tn {dtype} safe={safe} {M}x{N1}x{N2}', C.cpu(), ref, 2e-3 if dtype == torch.bfloat16 else 1e-3)
+    monkeypatch.setenv('VTX_TN_SAFE', '0')
+    C0 = torch.ones(N1, N2, device=DEV)
+    ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2, out=C0, accumulate=True)
+    check(f'gemm_tn accumulate {dtype}', C0.cpu(), ref + 1, 2e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gemm_tn_rowmap_and_colsum(dtype):
+    from vtx import ops
+    B, N, D1, D2 = 3, 50, 128, 64
+    X = rnd(B, 1 + N, D1, seed=1)
+    Y = rnd(B * N, D2, seed=2)
+    tm = ops.tokmap(N)
+    ref = q(X, dtype)[:, 1:].reshape(B * N, D1).t() @ q(Y, dtype)
+    C = ops.gemm_tn(dev(X, dtype), dev(Y, dtype), B * N, D1, D2, amap=tm)
+    check(f'gemm_tn rowmap {dtype}', C.cpu(), ref, 2e-3)
+    cs = ops.colsum(dev(X, dtype), B * N, D1, amap=tm)
+    check(f'colsum rowmap {dtype}', cs.cpu(), q(X, dtype)[:, 1:].reshape(-1, D1).sum(0), 1e-3)
+    big = rnd(5000, 2304, seed=3)
+    cs = ops.colsum(dev(big, dtype), 5000, 2304)
+    check(f'colsum big {dtype}', cs.cpu(), q(big, dtype).sum(0), 1e-3)
+
+
+# ---------------------------------------------------------------------------- attention
+def _attn_ref(qkv, heads):
+    Bn, L, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // heads
+    t = qkv.reshape(Bn, L, 3, heads, hd)
+    qq, kk, vv = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(qq @ kk.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    return (p @ vv).permute(0, 2, 1, 3).reshape(Bn, L, D), p
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('S,L', [(37, 8), (5, 9), (3, 17), (2, 64), (2, 65), (2, 197), (1, 300)])
+def test_attention_contig(dtype, S, L):
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG
+    H, hd = 2, 64
+    D = H * hd
+    qkv = rnd(S, L, 3 * D, seed=L) * 1.5
+    do = rnd(S, L, D, seed=L + 1)
+    qq = q(qkv, dtype).requires_grad_(True)
+    ref, p_ref = _attn_ref(qq, H)
+    ref.backward(q(do, dtype))
+    qd = dev(qkv, dtype)
+    o = torch.empty(S, L, D, dtype=dtype, device=DEV)
+    lse = torch.empty(S * H * L, device=DEV)
+    probs = torch.empty(S, H, L, L, device=DEV)
+    ops.attn_fwd(qd, o, lse, ATTN_CONTIG, S, L, H, hd, hd ** -0.5, probs=probs)
+    check(f'attn fwd {dtype} S={S} L={L}', o.float().cpu(), ref.detach(), TOL[dtype])
+    check(f'attn probs {dtype} S={S} L={L}', probs.cpu(), p_ref.detach(), 1e-3)
+    dqkv = torch.full((S, L, 3 * D), float('nan'), dtype=dtype, device=DEV)
+    ops.attn_bwd(qd, o, lse, dev(do, dtype), dqkv, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+    check(f'attn bwd {dtype} S={S} L={L}', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_attention_space_mode(dtype):
+    """Divided spatial attention addressing: natural-order qkv in, [tokens | per-frame cls] out."""
+    from vtx import ops
+    from vtx._lib import ATTN_SPACE
+    B, T, P, H, hd = 2, 4, 9, 2, 64
+    D = H * hd
+    N = P * T
+    qkv = rnd(B, 1 + N, 3 * D, seed=1) * 1.5
+    do_tok = rnd(B, N, D, seed=2)
+    do_cls = rnd(B * T, D, seed=3)
+    qq = q(qkv, dtype).requires_grad_(True)
+    tok = qq[:, 1:].reshape(B, P, T, 3 * D).permute(0, 2, 1, 3).reshape(B * T, P, 3 * D)
+    cls = qq[:, :1].expand(B, T, 3 * D).reshape(B * T, 1, 3 * D)
+    ref, _ = _attn_ref(torch.cat([cls, tok], 1), H)                    # [(b t), 1+P, D]
+    ref_tok = ref[:, 1:].reshape(B, T, P, D).permute(0, 2, 1, 3).reshape(B, N, D)
+    ref_cls = ref[:, 0]
+    (ref_tok * q(do_tok, dtype)).sum().backward(retain_graph=True)
+    (ref_cls * q(do_cls, dtype)).sum().backward()
+    qd = dev(qkv, dtype)
+    o = torch.empty(B * N + B * T, D, dtype=dtype, device=DEV)
+    lse = torch.empty(B * T * H * (P + 1), device=DEV)
+    ops.attn_fwd(qd, o, lse, ATTN_SPACE, B * T, P + 1, H, hd, hd ** -0.5, B, T, P)
+    check(f'attn space tokens {dtype}', o[:B * N].float().cpu().reshape(B, N, D), ref_tok.detach(), TOL[dtype])
+    check(f'attn space cls {dtype}', o[B * N:].float().cpu(), ref_cls.detach(), TOL[dtype])
+    do = torch.cat([do_tok.reshape(B * N, D), do_cls], 0)
+    dqkv = torch.zeros(B, 1 + N, 3 * D, dtype=dtype, device=DEV)
+    dqkv_cls = torch.empty(B * T, 3 * D, dtype=dtype, device=DEV)
+    ops.attn_bwd(qd, o, lse, dev(do, dtype), dqkv, ATTN_SPACE, B * T, P + 1, H, hd, hd ** -0.5, B, T, P, dqkv_cls=dqkv_cls)
+    ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, 1 + N)
+    check(f'attn space bwd {dtype}', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
+
+
+# ----------------------------------------------------------------------------- glue ops
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_glue_ops(dtype):
+    from vtx import ops
+    B, T, P, D = 2, 4, 5, 64
+    N = P * T
+    a_cls, x = rnd(B * T, D, seed=1), rnd(B, 1 + N, D, seed=2)
+    out = torch.zeros(B, 1 + N, D, dtype=dtype, device=DEV)
+    ops.cls_mean_fwd(dev(a_cls, dtype), dev(x, dtype), out, B, T, D, 1 + N)
+    ref = q(x, dtype)[:, 0] + q(a_cls, dtype).reshape(B, T, D).mean(1)
+    check(f'cls_mean {dtype}', out[:, 0].float().cpu(), ref, TOL[dtype])
+    s = torch.rand(B * T, generator=torch.Generator().manual_seed(3))
+    dout = rnd(B, 1 + N, D, seed=4)
+    da = torch.empty(B * N + B * T, D, dtype=dtype, device=DEV)
+    ops.space_grad_prep(dev(dout, dtype), dev(s), da, B, T, P, D)
+    dq = q(dout, dtype)
+    n = torch.arange(N)
+    ref_tok = dq[:, 1:] * s.double().reshape(B, T)[:, n % T][:, :, None]
+    ref_cls = (dq[:, :1] * s.double().reshape(B, T, 1) / T).reshape(B * T, D)
+    check(f'space_grad_prep tok {dtype}', da[:B * N].float().cpu().reshape(B, N, D), ref_tok, TOL[dtype])
+    check(f'space_grad_prep cls {dtype}', da[B * N:].float().cpu(), ref_cls, TOL[dtype])
+    # strided row reductions
+    r = ops.reduce_rows(dev(dout, dtype), N, B, D, D, 1, 1 + N, 1)
+    check(f'reduce_rows batch {dtype}', r.cpu(), dq[:, 1:].sum(0), 1e-3)
+    r2 = ops.reduce_rows(r, P, T, D, D, 0, 1, T)
+    check(f'reduce_rows pos {dtype}', r2.cpu(), dq[:, 1:].sum(0).reshape(P, T, D).sum(1), 1e-3)
+    r3 = ops.reduce_rows(r, T, P, D, D, 0, T, 1)
+    check(f'reduce_rows time {dtype}', r3.cpu(), dq[:, 1:].sum(0).reshape(P, T, D).sum(0), 1e-3)
+    # weight staging
+    W = rnd(96, 200, seed=5)
+    wc, wt = ops.cast_transpose(dev(W), dtype)
+    check(f'cast {dtype}', wc.float().cpu(), q(W, dtype), 1e-6)
+    check(f'cast_transpose {dtype}', wt.float().cpu(), q(W, dtype).t(), 1e-6)
+    # row broadcast / cls-row copy
+    src = rnd(D, seed=6)
+    dst = torch.zeros(B, 1 + N, D, dtype=dtype, device=DEV)
+    ops.row_scale_copy(dev(src, dtype), dst, B, D, smap=ops.rowmap(1, -1, 0), dmap=ops.clsmap(N))
+    check(f'cls row broadcast {dtype}', dst[:, 0].float().cpu(), q(src, dtype)[None].expand(B, D), 1e-6)
+    assert dst[:, 1:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('ts', [1, 2])
+def test_patch_rows_bit_exact(ts):
+    """Patch / tubelet indexing must be bit-exact (fp32 path: pure data movement)."""
+    from oracle import vt_oracle as O
+    from vtx import ops
+    B, T, C, H, W, ps = 2, 4, 3, 64, 48, 16
+    x = rnd(B, T, C, H, W, seed=1)
+    want = (O.patch_rows_2d(x, ps) if ts == 1 else O.patch_rows_3d(x, ps, ts))      # [(b t'), P, K]
+    Tq, P = T // ts, (H // ps) * (W // ps)
+    got = ops.patch_rows(dev(x), torch.float32, ps, ts, frame_major=True).cpu()
+    assert torch.equal(got, want.reshape(B * Tq * P, -1)), 'frame-major patch rows differ'
+    got = ops.patch_rows(dev(x), torch.float32, ps, ts, frame_major=False).cpu()
+    want_pt = want.reshape(B, Tq, P, -1).permute(0, 2, 1, 3).reshape(B * P * Tq, -1)
+    assert torch.equal(got, want_pt), 'token-order patch rows differ'
+    report(f'ok   patch_rows bit-exact ts={ts}')
+
+
+# ---------------------------------------------------------------------------------- HOG
+def _hog_frames():
+    fr = [np.random.RandomState(s).randint(0, 256, (224, 224, 3)).astype(np.uint8) for s in (1234, 7)]
+    yy, xx = np.mgrid[0:224, 0:224]
+    fr.append(np.stack([(yy * 255 // 223), (xx * 255 // 223), ((xx * 3 + yy * 5) // 8 % 256)], -1).astype(np.uint8))
+    return np.stack(fr)
+
+
+def test_hog_bit_exact_vs_skimage_golden():
+    from oracle import hog_oracle as H
+    from vtx import ops
+    frames = _hog_frames()
+    feats, bins = ops.hog_fwd(torch.from_numpy(frames).to(DEV), want_bins=True)
+    feats, bins = feats.cpu().numpy(), bins.cpu().numpy()
+    ref = gold('hog_skimage.npz')['feats']
+    for i in range(3):
+        assert np.array_equal(bins[i], H.hog_bin_map(frames[i])), f'frame {i}: orientation bins differ'
+        nbad = int((feats[i] != ref[i]).sum())
+        report(f'hog frame {i}: {nbad} of {ref[i].size} feature values differ, max abs {np.abs(feats[i] - ref[i]).max():.3e}')
+        assert nbad == 0, f'frame {i}: HOG features not bit-exact ({nbad} differ)'
+
+
+def test_hog_other_sizes_and_edges():
+    from oracle import hog_oracle as H
+    from vtx import ops
+    rs = np.random.RandomState(3)
+    for shape in [(32, 48), (16, 16), (224, 224)]:
+        fr = rs.randint(0, 256, (2,) + shape + (3,)).astype(np.uint8)
+        fr[1] = 0 if shape != (224, 224) else 255                    # constant frame -> all zeros
+        got = ops.hog_fwd(torch.from_numpy(fr).to(DEV)).cpu().numpy()
+        for i in range(2):
+            want = H.extract_hog_features(fr[i]) if shape == (224, 224) else _hog_any(fr[i])
+            assert np.array_equal(got[i], want), (shape, i)
+    assert ops.hog_fwd(torch.zeros(0, 32, 32, 3, dtype=torch.uint8, device=DEV)).shape == (0, 2, 2, 108)
+    report('ok   hog sizes/edges bit-exact')
+
+
+def _hog_any(img):
+    """oracle for sizes other than 224 (extract_hog_features hard-codes ph=pw=14 like the reference)."""
+    from oracle import hog_oracle as H
+    per = [H.hog_channel(img[:, :, c]) for c in range(3)]
+    f = np.concatenate(per, axis=-1)
+    nr, nc, k = f.shape
+    return f.reshape(nr // 2, 2, nc // 2, 2, k).transpose(0, 2, 1, 3, 4).reshape(nr // 2, nc // 2, 4 * k)
+
+
+# ------------------------------------------------------------------------ MaskFeat head
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_maskfeat_kernels(dtype):
+    import vtx
+    from oracle import vt_oracle as O
+    from vtx import ops
+    B, Tq, g, r, C = 2, 4, 3, 2, 32
+    Hq = g * r
+    L = Tq * Hq * Hq
+    x = rnd(B, L, C, seed=1)
+    mask = (torch.rand(B, Tq, g, g, generator=torch.Generator().manual_seed(2)) > 0.5).to(torch.int32)
+    tok = rnd(1, 1, C, seed=3)
+    xq = q(x, dtype).requires_grad_(True)
+    tq_ = tok.double().requires_grad_(True)
+    ref = O.maskfeat_blend(xq, mask, tq_, r)
+    dy = rnd(B, L, C, seed=4)
+    ref.backward(q(dy, dtype))
+    out = torch.empty(B, L, C, dtype=dtype, device=DEV)
+    m8 = dev(mask.to(torch.uint8))
+    vtx._lib.call('vtx_maskfeat_blend_fwd', ops.dt(out), B, Tq, Hq, Hq, C, g, ops.ptr(dev(x, dtype)), ops.ptr(m8),
+                  ops.ptr(dev(tok.reshape(-1))), ops.ptr(out), ops.stream())
+    check(f'maskfeat blend {dtype}', out.float().cpu(), ref.detach(), TOL[dtype])
+    dx = torch.empty(B, L, C, dtype=dtype, device=DEV)
+    dtok = torch.empty(C, device=DEV)
+    vtx._lib.call('vtx_maskfeat_blend_bwd', ops.dt(out), B, Tq, Hq, Hq, C, g, ops.ptr(dev(dy, dtype)), ops.ptr(m8),
+                  ops.ptr(dx), ops.ptr(dtok), ops.stream())
+    check(f'maskfeat blend dx {dtype}', dx.float().cpu(), xq.grad, TOL[dtype])
+    check(f'maskfeat blend dtoken {dtype}', dtok.cpu(), tq_.grad.reshape(-1), 1e-3)
+    # masked MSE
+    ts, Cf = 2, 24
+    pred = rnd(B, Tq * g * g, ts * Cf, seed=5)
+    target = torch.rand(B, Tq * ts, g, g, Cf, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    cm = (torch.rand(B, Tq * ts, g, g, generator=torch.Generator().manual_seed(7)) > 0.6)
+    pq = q(pred, dtype).requires_grad_(True)
+    p5 = pq.reshape(B, Tq, g, g, ts, Cf).permute(0, 1, 4, 2, 3, 5).reshape(B, Tq * ts, g, g, Cf)
+    err = ((p5 - target) ** 2).mean(-1)
+    loss_ref = (err * cm).sum() / (cm.sum() + 1e-5)
+    loss_ref.backward()
+    acc = torch.empty(2, dtype=torch.float64, device=DEV)
+    pd = dev(pred, dtype)
+    vtx._lib.call('vtx_maskfeat_loss_fwd', ops.dt(pd), B, Tq, ts, g, Cf, ops.ptr(pd), ts * Cf, ops.ptr(dev(target)),
+                  ops.ptr(dev(cm.to(torch.uint8))), ops.ptr(acc), ops.stream())
+    assert abs(acc[0].item() - loss_ref.item()) / loss_ref.item() < 1e-9, (acc, loss_ref)
+    dp = torch.empty_like(pd)
+    vtx._lib.call('vtx_maskfeat_loss_bwd', ops.dt(pd), B, Tq, ts, g, Cf, ops.ptr(pd), ts * Cf, ops.ptr(dev(target)),
+                  ops.ptr(dev(cm.to(torch.uint8))), ops.ptr(acc), 1.0, ops.ptr(dp), ts * Cf, ops.stream())
+    check(f'maskfeat loss grad {dtype}', dp.float().cpu(), pq.grad, TOL[dtype])
+    report(f'ok   maskfeat loss {dtype}: {acc[0].item():.12f} vs {loss_ref.item():.12f}')

@@ -1,0 +1,221 @@
+"""Model-level parity of the HIP path (through the drop-in nn.Module API and the C ABI)
+against (a) the committed golden vectors generated from the reference and (b) the CPU oracle.
+
+Bars (tests/helpers.py): fp32 path 1e-3 relative (north_star); bf16 path 3e-2 on outputs and
+6e-2 on parameter gradients versus the same fp32 reference (a bf16-autocast CPU run of the
+reference itself deviates by 8.6e-3 after 12 layers).
+All weights come from oracle/synth.py: temporal_fc is NOT zero, so the temporal kernels matter.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_BF16, TOL_BF16_GRAD, TOL_F32, check, compare_grads, gold, relerr, report
+from oracle import synth, vt_oracle as O
+from oracle.synth import synth_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SMALL = dict(img_size=64, patch_size=16, embed_dims=128, num_heads=2, num_transformer_layers=2)
+PRECS = [('fp32', TOL_F32, TOL_F32), ('bf16', TOL_BF16, TOL_BF16_GRAD)]
+
+
+@pytest.fixture(autouse=True)
+def _reset_precision():
+    import vtx
+    yield
+    vtx.set_precision('auto')
+
+
+def _build(cls, seed, **kw):
+    m = cls(**kw)
+    sd = synth.synth_state_dict(synth.shapes_of(m), seed)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV), sd
+
+
+def _train_step(m, x, seed, d):
+    m.train()
+    m.zero_grad()
+    torch.manual_seed(seed)
+    y = m(x.to(DEV))
+    w = (synth_tensor('loss_w', (d,), 0) * 10.0).to(DEV)
+    (y * w).sum().backward()
+    torch.cuda.synchronize()
+    return y, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+@pytest.mark.parametrize('at', ['divided_space_time', 'space_only', 'joint_space_time'])
+def test_timesformer_small_vs_golden(at, prec, tol, gtol):
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold(f'tsf_small_{at}.npz')
+    m, _ = _build(V.TimeSformer, 3, num_frames=4, attention_type=at, **SMALL)
+    x = synth.synth_clip(3, 4, 3, 64, 64, seed=2)
+    y, grads = _train_step(m, x, 11, 128)
+    assert y.dtype == torch.float32 and y.shape == (3, 128)
+    check(f'tsf_small {at} {prec} train out', y.cpu(), g['out'], tol)
+    compare_grads(f'tsf_small {at} {prec}', grads, g, gtol)
+    m.eval()
+    with torch.no_grad():
+        check(f'tsf_small {at} {prec} eval out', m(x.to(DEV)).cpu(), g['out_eval'], tol)
+        att = m.get_last_selfattention(x.to(DEV))
+    assert tuple(att.shape) == g['attn'].shape
+    check(f'tsf_small {at} {prec} last attention', att.cpu(), g['attn'], tol)
+    assert abs(att.sum(-1).cpu() - 1).max().item() < 1e-3
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+@pytest.mark.parametrize('at', ['fact_encoder', 'joint_space_time', 'divided_space_time'])
+def test_vivit_small_vs_golden(at, prec, tol, gtol):
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold(f'vivit_small_{at}.npz')
+    m, _ = _build(V.ViViT, 4, num_frames=8, attention_type=at, **SMALL)
+    x = synth.synth_clip(3, 8, 3, 64, 64, seed=5)
+    y, grads = _train_step(m, x, 13, 128)
+    check(f'vivit_small {at} {prec} train out', y.cpu(), g['out'], tol)
+    compare_grads(f'vivit_small {at} {prec}', grads, g, gtol)
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
+def test_timesformer_b_cfg1_forward(prec, tol):
+    """BASELINE.json configs[0]: TimeSformer-B divided_space_time, 2 frames, batch 2, forward."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    m, _ = _build(V.TimeSformer, 0, num_frames=2)
+    m.eval()
+    with torch.no_grad():
+        y = m(synth.synth_clip(2, 2, seed=0).to(DEV))
+    check(f'TimeSformer-B cfg1 {prec}', y.cpu(), gold('tsf_b_cfg1.npz')['out'], tol)
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+def test_timesformer_b_t8_train_vs_golden(prec, tol, gtol):
+    """BASELINE.json configs[1] shape (TimeSformer-B, 8x224^2), train mode with DropPath, fwd+bwd."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold('tsf_b_t8_train.npz')
+    m, _ = _build(V.TimeSformer, 0, num_frames=8)
+    y, grads = _train_step(m, synth.synth_clip(1, 8, seed=1), 7, 768)
+    check(f'TimeSformer-B T=8 train {prec} out', y.cpu(), g['out'], tol)
+    compare_grads(f'TimeSformer-B T=8 train {prec}', grads, g, gtol)
+    ge = gold('tsf_b_t8_eval.npz')
+    m.eval()
+    with torch.no_grad():
+        x = synth.synth_clip(1, 8, seed=1).to(DEV)
+        check(f'TimeSformer-B T=8 eval {prec} out', m(x).cpu(), ge['out'], tol)
+        att = m.get_last_selfattention(x)
+    assert list(att.shape) == list(ge['attn_shape'])                 # [8, 12, 197, 197]
+    check(f'TimeSformer-B T=8 {prec} attention', att[:2, :, :8, :8].cpu(), ge['attn_head'], tol)
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
+def test_vivit_b_forward(prec, tol):
+    """BASELINE.json configs[2] shape: ViViT-B fact_encoder, Conv3d tubelets, 16 frames."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    m, _ = _build(V.ViViT, 0, num_frames=16)
+    m.eval()
+    with torch.no_grad():
+        y = m(synth.synth_clip(2, 16, seed=3).to(DEV))
+    check(f'ViViT-B fact_encoder {prec}', y.cpu(), gold('vivit_b_t16_eval.npz')['out'], tol)
+
+
+def test_batch_and_length_properties():
+    """Size-independent properties at full width: clips are independent (a clip's output does not
+    depend on its batch neighbours) and eval forward is deterministic."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision('bf16')
+    m, _ = _build(V.TimeSformer, 0, num_frames=8)
+    m.eval()
+    x = synth.synth_clip(3, 8, seed=4).to(DEV)
+    with torch.no_grad():
+        y3 = m(x)
+        y1 = m(x[1:2])
+        y3b = m(x)
+    assert torch.equal(y3, y3b), 'eval forward must be deterministic'
+    check('clip independence (bf16, B=3 vs B=1)', y1.cpu(), y3[1:2].cpu(), 1e-6)
+
+
+def test_autocast_selects_bf16_path():
+    import vtx
+    import video_transformer as V
+    m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
+    m.eval()
+    x = synth.synth_clip(2, 4, 3, 64, 64, seed=2).to(DEV)
+    with torch.no_grad():
+        y32 = m(x)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y16 = m(x)
+        vtx.set_precision('bf16')
+        yb = m(x)
+    assert torch.equal(y16, yb) and not torch.equal(y16, y32)
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
+def test_maskfeat_head_vs_golden(prec, tol):
+    """MaskFeat head (blend + decoder + centre-frame masked MSE) against the reference's own
+    MaskFeat.forward run on a stand-in backbone (tests/golden/make_golden.py)."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold('maskfeat_head.npz')
+    mask = torch.from_numpy(g['mask'])
+    markers = json.loads(str(g['markers']))
+
+    class StandIn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer('w', synth_tensor('standin.w', (768, 96), 0))
+
+        def forward(self, t):
+            t = t.float()
+            b = t.shape[0]
+            v = t.reshape(b, 8, 14, 4, 14, 4, 96).mean(dim=(3, 5)).reshape(b, 1568, 96) @ self.w.t()
+            return torch.cat([v.mean(1, keepdim=True), v], dim=1)
+
+    m = V.MaskFeat(pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]], feature_dim=2 * 2 * 2 * 3 * 9, backbone=StandIn())
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if 'mvit' not in k}, seed=6)
+    m.load_state_dict(sd, strict=False)
+    m.to(DEV).train()
+    x = synth.synth_clip(2, 16, seed=8).to(DEV)
+    target = torch.rand(2, 16, 14, 14, 108, generator=torch.Generator().manual_seed(99), dtype=torch.float64)
+    pred, loss = m(x, target.to(DEV), mask.to(DEV), markers)
+    loss.backward()
+    assert pred.shape == (2, 16, 14, 14, 108) and loss.dtype == torch.float64
+    rel = abs(loss.item() - float(g['loss'])) / float(g['loss'])
+    report(f'maskfeat {prec}: loss {loss.item():.9f} vs reference {float(g["loss"]):.9f} (rel {rel:.2e})')
+    assert rel < tol
+    check(f'maskfeat {prec} pred', pred[:, :, :2, :2].cpu(), g['pred_head'], tol)
+    check(f'maskfeat {prec} d decoder bias', m.decoder_pred.bias.grad.cpu(), g['d_decoder_b'], 2 * tol)
+    check(f'maskfeat {prec} d decoder weight', m.decoder_pred.weight.grad[:8].cpu(), g['d_decoder_w_head'], 2 * tol)
+    check(f'maskfeat {prec} d mask_token', m.mask_token.grad.cpu(), g['d_mask_token'], 4 * tol)
+
+
+def test_hip_vs_oracle_fresh_seed():
+    """Independent of the goldens: a new seed, oracle run on this host."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision('fp32')
+    m, sd = _build(V.TimeSformer, 21, num_frames=8, img_size=96, patch_size=16, embed_dims=192, num_heads=3,
+                   num_transformer_layers=3)
+    x = synth.synth_clip(2, 8, 3, 96, 96, seed=22)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.manual_seed(5)
+    yo = O.timesformer_forward(sdo, x, 8, heads=3, layers=3, training=True)
+    (yo * synth_tensor('loss_w', (192,), 0) * 10.0).sum().backward()
+    y, grads = _train_step(m, x, 5, 192)
+    check('fresh-seed fp32 out vs oracle', y.cpu(), yo.detach(), TOL_F32)
+    worst = max(relerr(grads[k].cpu(), sdo[k].grad) for k in grads)
+    report(f'fresh-seed fp32: {len(grads)} grads, worst rel {worst:.3e}')
+    assert worst < TOL_F32

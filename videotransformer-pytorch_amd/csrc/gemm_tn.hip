@@ -314,7 +314,8 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   if (d->dtype == VTX_BF16) {
     const size_t need = (size_t)2 * TN_BKM * TN_LD * 2;
     const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;
-    static const bool safe = getenv("VTX_TN_SAFE") && atoi(getenv("VTX_TN_SAFE")) != 0;
+    const char* safe_env = getenv("VTX_TN_SAFE");   // diagnostic path, read per call
+    const bool safe = safe_env && atoi(safe_env) != 0;
     if (safe)
       hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, block, lds, st, d->M, m_per, (const bf16raw*)d->A, d->lda,
                          d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1 * tiles2, out);

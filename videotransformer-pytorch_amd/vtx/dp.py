@@ -1,0 +1,117 @@
+"""Data-parallel gradient exchange for the clip-sharded training step.
+
+The reference gets this implicitly from Lightning's ``accelerator="ddp"``
+(model_pretrain.py:200-204): clips are independent, every rank holds a full replica,
+and the only exchange per step is a mean all-reduce of the parameter gradients.
+
+Here: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL on ROCm) over
+xGMI.  Gradients live in a few flat fp32 buffers (``param.grad`` are views), bucketed
+per transformer layer in reverse registration order = the order backward produces them.
+A bucket's all-reduce is issued asynchronously from the post-accumulate hook of its last
+parameter, so the exchange of layer i+1 overlaps the backward kernels of layer i; the
+step ends with ``finish()`` (wait + 1/world scaling folded into the reduce op).
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of S bytes is
+bound by 2*(7/8)*S / link rate, so buckets are large (one layer, ~40 MB fp32) rather
+than torch DDP's NVSwitch-era 25 MB default.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, comm_dtype=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype            # e.g. torch.bfloat16 to halve xGMI bytes (lossy)
+        params = [p for p in params if p.requires_grad]
+        order = list(reversed(params))
+        self.buckets = []                       # each: dict(params, flat, pending, handle)
+        cur, cur_bytes = [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._close(cur)
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b['params']:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self._launched = []
+
+    def _close(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append(dict(params=plist, flat=flat, pending=len(plist), handle=None, comm=None))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            b = self.buckets[bi]
+            b['pending'] -= 1
+            if b['pending'] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.world == 1:
+            return
+        buf = b['flat']
+        if self.comm_dtype is not None and self.comm_dtype != buf.dtype:
+            b['comm'] = buf.to(self.comm_dtype)
+            buf = b['comm']
+        op = dist.ReduceOp.AVG if dist.get_backend(self.group) == 'nccl' else dist.ReduceOp.SUM
+        b['handle'] = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+        b['avg_in_op'] = op == dist.ReduceOp.AVG
+        self._launched.append(b)
+
+    def zero(self):
+        """Zero the flat gradient buffers (use instead of optimizer.zero_grad(set_to_none=True):
+        the .grad views must stay bound to the buckets)."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'] = len(b['params'])
+            b['handle'] = None
+            b['comm'] = None
+        self._launched = []
+
+    def finish(self):
+        """Wait for every bucket's all-reduce; afterwards param.grad holds the mean gradient."""
+        for b in self._launched:
+            b['handle'].wait()
+            if b['comm'] is not None:
+                b['flat'].copy_(b['comm'])
+            if not b['avg_in_op']:
+                b['flat'].div_(self.world)
+        # buckets whose hooks never all fired (unused parameters): reduce them now
+        if self.world > 1:
+            for b in self.buckets:
+                if b['handle'] is None:
+                    dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
+                    b['flat'].div_(self.world)
+        self._launched = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """One-time rank-0 -> all parameter broadcast (what DDP does at wrap time)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def shard_clips(global_batch, rank, world):
+    """Clips are the independent units: rank r takes clips r, r+world, ... of the global batch."""
+    return list(range(rank, global_batch, world))

@@ -50,6 +50,43 @@ def clsmap(n_tokens):
     return RowMap(1, int(n_tokens), 0)
 
 
+# ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream ----
+_prof = None
+
+
+def profile_start(classes=('gemm_nt',)):
+    global _prof
+    _prof = {c: [] for c in classes}
+
+
+def profile_stop():
+    """-> {class: (n_launches, total_ms, total_work)}; call after torch.cuda.synchronize()."""
+    global _prof
+    out = {}
+    for c, recs in (_prof or {}).items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        out[c] = (len(recs), ms, sum(w for _, _, w in recs))
+    _prof = None
+    return out
+
+
+class _timed:
+    def __init__(self, cls, work):
+        self.on = _prof is not None and cls in _prof
+        self.cls, self.work = cls, work
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            _prof[self.cls].append((self.e0, self.e1, self.work))
+
+
 def _f32(t):
     if t is not None and t.dtype != torch.float32:
         raise TypeError('vtx: parameter tensors must be float32')
@@ -59,16 +96,18 @@ def _f32(t):
 # ------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, rows, D, ldx, xmap, gamma, beta, eps, y, ldy, ymap=IDENT, mean=None, rstd=None):
     need_cuda(x, y, gamma, beta)
-    call('vtx_layernorm_fwd', dt(x), rows, D, ptr(x), ldx, xmap, ptr(_f32(gamma)), ptr(_f32(beta)), float(eps),
-         ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
+    with _timed('ln_fwd', 2.0 * rows * D * x.element_size()):
+        call('vtx_layernorm_fwd', dt(x), rows, D, ptr(x), ldx, xmap, ptr(_f32(gamma)), ptr(_f32(beta)), float(eps),
+             ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
 
 
 def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dres, dx, lddx, dgamma, dbeta):
     need_cuda(dy, x, dx)
     ws_bytes = _lib.load().vtx_layernorm_bwd_workspace(rows, D)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-    call('vtx_layernorm_bwd', dt(x), rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd),
-         ptr(gamma), ptr(dres), ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, stream())
+    with _timed('ln_bwd', (4.0 if dres is not None else 3.0) * rows * D * x.element_size()):
+        call('vtx_layernorm_bwd', dt(x), rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd),
+             ptr(gamma), ptr(dres), ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, stream())
 
 
 # ----------------------------------------------------------------------- GEMM
@@ -90,7 +129,8 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
     d.row_scale = ptr(_f32(row_scale)); d.rs_d1, d.rs_m1, d.rs_d2, d.rs_m2 = [int(v) for v in rs]
     d.R = ptr(R); d.ldr = (N if ldr is None else ldr); d.rmap = rmap; d.r_period = int(r_period)
     d.split_row = int(split_row); d.Csplit = ptr(Csplit); d.ldsplit = N
-    call('vtx_gemm_nt', C.byref(d), stream())
+    with _timed('gemm_nt', 2.0 * M * N * K):
+        call('vtx_gemm_nt', C.byref(d), stream())
 
 
 def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDENT, accumulate=False):
@@ -106,7 +146,8 @@ def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDEN
     d.B = ptr(B); d.ldb = N2 if ldb is None else ldb; d.bmap = bmap
     d.C = ptr(out); d.ldc = N2; d.accumulate = int(bool(accumulate))
     d.workspace = ptr(ws); d.ws_bytes = ws_bytes
-    call('vtx_gemm_tn', C.byref(d), stream())
+    with _timed('gemm_tn', 2.0 * M * N1 * N2):
+        call('vtx_gemm_tn', C.byref(d), stream())
     return out
 
 
@@ -116,8 +157,9 @@ def colsum(A, M, N, lda=None, amap=IDENT, out=None, accumulate=False):
         out = torch.empty(N, dtype=torch.float32, device=A.device)
     ws_bytes = _lib.load().vtx_colsum_workspace(M, N)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
-    call('vtx_colsum', dt(A), M, N, ptr(A), N if lda is None else lda, amap, ptr(out), int(bool(accumulate)),
-         ptr(ws), ws_bytes, stream())
+    with _timed('colsum', 1.0 * M * N * A.element_size()):
+        call('vtx_colsum', dt(A), M, N, ptr(A), N if lda is None else lda, amap, ptr(out), int(bool(accumulate)),
+             ptr(ws), ws_bytes, stream())
     return out
 
 
@@ -136,7 +178,8 @@ def _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B=0, T=0, P=0, probs=Non
 def attn_fwd(qkv, out, lse, mode, S, L, H, hd, scale, B=0, T=0, P=0, probs=None):
     need_cuda(qkv, out, lse)
     d = _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B, T, P, probs)
-    call('vtx_attn_fwd', C.byref(d), stream())
+    with _timed('attn_fwd', 4.0 * S * H * L * L * hd):
+        call('vtx_attn_fwd', C.byref(d), stream())
 
 
 def attn_bwd(qkv, out, lse, dout, dqkv, mode, S, L, H, hd, scale, B=0, T=0, P=0, dqkv_cls=None):
@@ -148,7 +191,8 @@ def attn_bwd(qkv, out, lse, dout, dqkv, mode, S, L, H, hd, scale, B=0, T=0, P=0,
     b.dqkv_cls = ptr(dqkv_cls)
     delta = torch.empty(S * H * L, dtype=torch.float32, device=qkv.device)
     b.delta = ptr(delta)
-    call('vtx_attn_bwd', C.byref(b), stream())
+    with _timed('attn_bwd', 10.0 * S * H * L * L * hd):
+        call('vtx_attn_bwd', C.byref(b), stream())
 
 
 # ------------------------------------------------------------------- glue ops
