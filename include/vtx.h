@@ -221,7 +221,7 @@ int vtx_maskfeat_blend_bwd(int dtype, int B, int Tq, int Hq, int Wq, int C, int 
  * by the call. */
 int vtx_maskfeat_loss_fwd(int dtype, int B, int Tq, int ts, int g, int Cf, const void* pred, long ldp,
                           const double* target, const uint8_t* cmask, double* loss_out, void* stream);
-/* dpred = gloss * 2 (pred - target) * cmask / (Cf * (sum(cmask) + 1e-5)) */
+/* dpred = gloss * 2 (pred - target) * cmask / (Cf * float32(sum(cmask) + 1e-5)) */
 int vtx_maskfeat_loss_bwd(int dtype, int B, int Tq, int ts, int g, int Cf, const void* pred, long ldp,
                           const double* target, const uint8_t* cmask, const double* loss_out,
                           float gloss, void* dpred, long lddp, void* stream);

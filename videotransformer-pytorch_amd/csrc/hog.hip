@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void mf_loss_fwd_kernel(long cells, int Tq, in
     atomicAdd(acc2 + 1, msum);
   }
 }
-__global__ void mf_loss_finish_kernel(double* acc2) { acc2[0] = acc2[0] / (acc2[1] + 1e-5); }
+// The reference computes `mask.sum() + 1e-5` on an int32 mask: the integer sum is promoted to
+// float32 (video_transformer.py:901), so the denominator is float32(sum + 1e-5).
+__device__ inline double mf_denominator(double msum) { return (double)((float)msum + 1e-5f); }
+__global__ void mf_loss_finish_kernel(double* acc2) { acc2[0] = acc2[0] / mf_denominator(acc2[1]); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mf_loss_bwd_kernel(long rows, int Tq, int ts, int g, int Cf, const T* __restrict__ pred,
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void mf_loss_bwd_kernel(long rows, int Tq, int
                                                           float gloss, T* __restrict__ dpred, long lddp) {
   // one thread per element of pred [rows, ts*Cf]
   const long total = rows * ts * Cf;
-  const double coef = (double)gloss * 2.0 / ((double)Cf * (acc2[1] + 1e-5));
+  const double coef = (double)gloss * 2.0 / ((double)Cf * mf_denominator(acc2[1]));
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const long row = idx / (ts * Cf);
     const int col = (int)(idx - row * (ts * Cf));
@@ -218,10 +221,10 @@ extern "C" int vtx_hog_build_table(double* host_table) {
 
 extern "C" int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table, double* out, int32_t* bins,
                            void* stream) {
-  VTX_REQUIRE(frames && table && out, VTX_EINVAL, "hog_fwd: null pointer");
   VTX_REQUIRE(F >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && W <= 1024, VTX_EINVAL,
               "hog_fwd: H=%d, W=%d must be multiples of 16 (W <= 1024)", H, W);
-  if (F == 0) return VTX_OK;
+  if (F == 0) return VTX_OK;                       // empty batch: nothing to do (pointers may be null)
+  VTX_REQUIRE(frames && table && out, VTX_EINVAL, "hog_fwd: null pointer");
   const size_t lds = ((10 * W + 15) & ~15) + (size_t)8 * W * 8 + ((8 * W + 15) & ~15) + (size_t)(W / 8) * 9 * 8;
   dim3 grid(H / 8, 3, F), block(256);
   hipLaunchKernelGGL(hog_kernel, grid, block, lds, as_stream(stream), frames, H, W, table, out, bins);

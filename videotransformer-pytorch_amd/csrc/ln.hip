@@ -176,20 +176,35 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(
   }
 }
 
-// out[n] (+)= sum_s part[s*stride + n], n < N.
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nslabs, long stride,
-                                       long N, float* __restrict__ out, int accumulate, float scale) {
-  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float a = 0.f;
-  for (int s = 0; s < nslabs; ++s) a += part[(long)s * stride + n];
-  a *= scale;
-  out[n] = accumulate ? out[n] + a : a;
+// out[n] (+)= scale * sum_s part[s*stride + n], n < N.  64 columns x 4 slab lanes per block:
+// coalesced 256-B row segments, independent loads in flight, fixed summation order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nslabs, long stride,
+                                                              long N, float* __restrict__ out, int accumulate, float scale) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  const long n = (long)blockIdx.x * 64 + cx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (n < N) {
+    int s = sy;
+    for (; s + 12 < nslabs; s += 16) {
+      a0 += part[(long)s * stride + n];
+      a1 += part[(long)(s + 4) * stride + n];
+      a2 += part[(long)(s + 8) * stride + n];
+      a3 += part[(long)(s + 12) * stride + n];
+    }
+    for (; s < nslabs; s += 4) a0 += part[(long)s * stride + n];
+  }
+  red[sy][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sy == 0 && n < N) {
+    const float a = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * scale;
+    out[n] = accumulate ? out[n] + a : a;
+  }
 }
 
 int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
                            int accumulate, float scale, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, nslabs,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, part, nslabs,
                      stride, N, out, accumulate, scale);
   return check_launch("reduce_partials");
 }
@@ -197,6 +212,11 @@ int launch_reduce_partials(const float* part, int nslabs, long stride, long N, f
 static int ln_blocks(int rows) {
   int b = cdiv(rows, LN_WAVES);
   return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
+// backward keeps per-block partial sums of dgamma/dbeta: fewer, fatter blocks
+static int ln_bwd_blocks(int rows) {
+  int b = cdiv(rows, LN_WAVES * 8);
+  return b > 512 ? 512 : (b < 1 ? 1 : b);
 }
 
 template <typename T>
@@ -264,7 +284,7 @@ extern "C" int vtx_layernorm_fwd(int dtype, int rows, int D, const void* x, long
 }
 
 extern "C" size_t vtx_layernorm_bwd_workspace(int rows, int D) {
-  return (size_t)ln_blocks(rows) * 2 * (size_t)D * sizeof(float);
+  return (size_t)ln_bwd_blocks(rows) * 2 * (size_t)D * sizeof(float);
 }
 
 extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy,
@@ -278,7 +298,7 @@ extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, lon
   VTX_REQUIRE(ws_bytes >= vtx_layernorm_bwd_workspace(rows, D), VTX_EWS, "layernorm_bwd: workspace too small");
   VTX_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
               VTX_EALIGN, "layernorm_bwd: 16-byte alignment required");
-  const int nb = ln_blocks(rows);
+  const int nb = ln_bwd_blocks(rows);
   float* part = (float*)workspace;
   hipStream_t st = as_stream(stream);
   int rc;
