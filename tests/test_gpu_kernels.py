@@ -218,11 +218,13 @@ def test_attention_contig(dtype, S, L):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_attention_space_mode(dtype):
-    """Divided spatial attention addressing: natural-order qkv in, [tokens | per-frame cls] out."""
+@pytest.mark.parametrize('B,T,P', [(2, 4, 9), (2, 3, 36), (1, 2, 196)])
+def test_attention_space_mode(dtype, B, T, P):
+    """Divided spatial attention addressing: natural-order qkv in, [tokens | per-frame cls] out.
+    P+1 <= 32 runs the VALU kernels, 33..256 the MFMA kernels (bf16)."""
     from vtx import ops
     from vtx._lib import ATTN_SPACE
-    B, T, P, H, hd = 2, 4, 9, 2, 64
+    H, hd = 2, 64
     D = H * hd
     N = P * T
     qkv = rnd(B, 1 + N, 3 * D, seed=1) * 1.5
@@ -248,6 +250,28 @@ def test_attention_space_mode(dtype):
     ops.attn_bwd(qd, o, lse, dev(do, dtype), dqkv, ATTN_SPACE, B * T, P + 1, H, hd, hd ** -0.5, B, T, P, dqkv_cls=dqkv_cls)
     ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, 1 + N)
     check(f'attn space bwd {dtype}', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
+
+
+def test_attention_mfma_matches_valu(monkeypatch):
+    """The bf16 MFMA kernels and the VALU kernels are two implementations of the same op."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG
+    S, L, H, hd = 3, 197, 3, 64
+    D = H * hd
+    qkv = dev(rnd(S, L, 3 * D, seed=5) * 1.5, torch.bfloat16)
+    do = dev(rnd(S, L, D, seed=6), torch.bfloat16)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('VTX_ATTN_VALU', mode)
+        o = torch.empty(S, L, D, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(S * H * L, device=DEV)
+        ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        dqkv = torch.full((S, L, 3 * D), float('nan'), dtype=torch.bfloat16, device=DEV)
+        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        res[mode] = (o.float().cpu(), lse.cpu(), dqkv.float().cpu())
+    check('attn mfma vs valu out', res['0'][0], res['1'][0], 1e-2)
+    check('attn mfma vs valu lse', res['0'][1], res['1'][1], 1e-4)
+    check('attn mfma vs valu dqkv', res['0'][2], res['1'][2], 2e-2)
 
 
 # ----------------------------------------------------------------------------- glue ops

@@ -12,7 +12,8 @@
 // workgroup; long ones (L = 197 spatial, 1569 joint) use one sequence per
 // workgroup and 64-key tiles.  Algorithmic bytes per (sequence, head):
 // read 3*L*hd, write L*hd elements (+ L fp32 lse).
-#include "common.h"
+#include <stdlib.h>
+#include "attn_common.h"
 
 namespace vtx {
 
@@ -20,24 +21,6 @@ constexpr int AT_THREADS = 256;    // long sequences: one sequence per workgroup
 constexpr int AT_PACK_THREADS = 128;  // short sequences: G = 128/L sequences per workgroup (64 KB of LDS tiles)
 constexpr int AT_KT = 64;      // keys (or queries, in the dk/dv pass) per LDS tile
 constexpr int AT_CH = 8;       // online-softmax chunk
-
-struct AttnP {
-  int mode, S, L, H, B, T, P;
-  long ld_qkv, ld_out, ld_dout, ld_dqkv;
-  float scale;
-  int G;                        // sequences per workgroup
-};
-
-__device__ inline long in_row(const AttnP& p, int s, int i) {
-  if (p.mode == VTX_ATTN_CONTIG) return (long)s * p.L + i;
-  const int b = s / p.T, t = s - b * p.T;
-  return (long)b * (1 + (long)p.P * p.T) + (i == 0 ? 0 : 1 + (long)(i - 1) * p.T + t);
-}
-__device__ inline long out_row(const AttnP& p, int s, int i) {
-  if (p.mode == VTX_ATTN_CONTIG) return (long)s * p.L + i;
-  const int b = s / p.T, t = s - b * p.T;
-  return i == 0 ? (long)p.B * p.P * p.T + s : (long)b * p.P * p.T + (long)(i - 1) * p.T + t;
-}
 
 template <int HD> struct Tile {           // one [rows][HD] fp32 tile per packed sequence, padded
   static constexpr int SEQ_PAD = 4;       // floats between packed sequences (bank spread for broadcast reads)
@@ -314,6 +297,13 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_bwd_dkv_kernel(AttnP p, co
   }
 }
 
+// bf16, head_dim 64, 33..256 tokens -> MFMA kernels (attn_mfma.hip); VTX_ATTN_VALU=1 forces the VALU path.
+static bool use_mfma(int dtype, int L, int hd) {
+  const char* e = getenv("VTX_ATTN_VALU");
+  if (e && atoi(e) != 0) return false;
+  return attn_mfma_eligible(dtype, L, hd);
+}
+
 static int make_params(const vtx_attn_desc* d, AttnP& p, const char* who) {
   VTX_REQUIRE(d->S > 0 && d->L > 0 && d->H > 0, VTX_EINVAL, "%s: bad shape S=%d L=%d H=%d", who, d->S, d->L, d->H);
   VTX_REQUIRE(d->hd == 64, VTX_EINVAL, "%s: head_dim %d unsupported (64 only)", who, d->hd);
@@ -354,11 +344,15 @@ extern "C" int vtx_attn_fwd(const vtx_attn_desc* d, void* stream) {
   hipStream_t st = as_stream(stream);
   const dim3 grid = attn_grid(p), block = attn_block(p);
   const size_t lds = attn_lds(p, 64, false);
-  if (d->dtype == VTX_F32)
-    hipLaunchKernelGGL((attn_fwd_kernel<float, 64, 0>), grid, block, lds, st, p, (const float*)d->qkv, (float*)d->out, d->lse, nullptr);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<bf16raw, 64, 0>), grid, block, lds, st, p, (const bf16raw*)d->qkv, (bf16raw*)d->out, d->lse, nullptr);
-  rc = check_launch("attn_fwd");
+  if (use_mfma(d->dtype, d->L, d->hd)) {
+    rc = attn_fwd_mfma_launch(p, d->qkv, d->out, d->lse, st);
+  } else {
+    if (d->dtype == VTX_F32)
+      hipLaunchKernelGGL((attn_fwd_kernel<float, 64, 0>), grid, block, lds, st, p, (const float*)d->qkv, (float*)d->out, d->lse, nullptr);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<bf16raw, 64, 0>), grid, block, lds, st, p, (const bf16raw*)d->qkv, (bf16raw*)d->out, d->lse, nullptr);
+    rc = check_launch("attn_fwd");
+  }
   if (rc || !d->probs) return rc;
   if (d->dtype == VTX_F32)
     hipLaunchKernelGGL((attn_fwd_kernel<float, 64, 1>), grid, block, lds, st, p, (const float*)d->qkv, (float*)d->out, d->lse, d->probs);
@@ -379,6 +373,8 @@ extern "C" int vtx_attn_bwd(const vtx_attn_bwd_desc* d, void* stream) {
   hipStream_t st = as_stream(stream);
   const dim3 grid = attn_grid(p), block = attn_block(p);
   const size_t lds_a = attn_lds(p, 64, false), lds_b = attn_lds(p, 64, true);
+  if (use_mfma(d->f.dtype, d->f.L, d->f.hd))
+    return attn_bwd_mfma_launch(p, d->f.qkv, d->f.out, d->dout, d->f.lse, d->delta, d->dqkv, d->dqkv_cls, st);
   if (d->f.dtype == VTX_F32) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<float, 64>), grid, block, lds_a, st, p, (const float*)d->f.qkv, (const float*)d->f.out,
                        (const float*)d->dout, d->f.lse, d->delta, (float*)d->dqkv, (float*)d->dqkv_cls);

@@ -1,0 +1,363 @@
+// attn_mfma.hip -- bf16 MFMA attention core for sequences of 33..256 tokens, head_dim 64
+// (the divided *spatial* attention of TimeSformer: L = 197; ViViT's spatial encoder).
+//
+// Reference: transformer.py:167-174 (q k^T * scale -> softmax -> @ v) plus the
+// '(b t) p d' regrouping / cls replication of :352-356,:375 done by row arithmetic
+// (in_row / out_row, shared with the VALU kernels in attn.hip).
+//
+// One workgroup (4 waves) per (sequence, head).  Whole K and V ([Lp][64] bf16, Lp = L
+// rounded up to 32) sit in LDS; each wave owns 32-row query tiles.  All products are
+// v_mfma_f32_32x32x16_bf16.  The score tile is computed TRANSPOSED (S^T = K Q^T) so that
+// in the MFMA C/D layout a lane owns one query column: softmax row statistics are
+// in-lane reductions plus one cross-half shuffle, and the probabilities are already
+// laid out as the B operand of O^T = V^T P^T -- no LDS round trip for P.  The 8-key
+// groups a lane holds are {0-3, 8-11} (lower half) / {4-7, 12-15} (upper half) of each
+// 16-key step; the V^T / K^T / Q^T / dO^T operands are fetched with the hardware
+// transpose read ds_read_b64_tr_b16 using the SAME key permutation, so no cross-lane
+// exchange is needed (a contraction is invariant to a consistent permutation of k).
+//
+// LDS tiles are [rows][64] bf16 with the 16-byte chunk index XOR-ed by
+// rev3((row>>1)&7): conflict-free both for the row-wise ds_read_b128 operand reads and
+// for the 4-row x 16-column blocks of the transpose reads.
+//
+// Backward = two kernels, mirroring the two contractions:
+//   dq : lanes = queries (S^T layout);  dQ^T += K^T dS^T          (+ writes delta)
+//   dkv: lanes = keys    (S layout);    dV^T += dO^T P, dK^T += Q^T dS
+// FLOPs per (sequence, head): fwd 4*Lp^2*64, bwd 14*Lp^2*64 (incl. recompute).
+#include "attn_common.h"
+
+namespace vtx {
+
+__device__ inline long m_in_row(const AttnP& p, int s, int i) { return in_row(p, s, i); }
+__device__ inline long m_out_row(const AttnP& p, int s, int i) { return out_row(p, s, i); }
+
+constexpr int MA_THREADS = 256;
+constexpr int MA_MAXT = 8;            // up to 8 tiles of 32 rows (Lp <= 256)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ inline int sw_of(int row) {
+  const int x = (row >> 1) & 7;
+  return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1);
+}
+// element offset of (row, col) in a swizzled [rows][64] bf16 tile
+__device__ inline int sw_off(int row, int col) { return row * 64 + ((((col >> 3) ^ sw_of(row))) << 3) + (col & 7); }
+
+// Fill a swizzled LDS tile with `nrows_valid` rows gathered through rowfn (zero rows beyond, up to Lp).
+template <typename RowFn>
+__device__ inline void fill_tile(bf16raw* lds, int Lp, int nvalid, const bf16raw* base, long ld, int col0, RowFn rowfn) {
+  for (int id = threadIdx.x; id < Lp * 8; id += MA_THREADS) {
+    const int r = id >> 3, c = id & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < nvalid) v = *reinterpret_cast<const uint4*>(base + rowfn(r) * ld + col0 + c * 8);
+    *reinterpret_cast<uint4*>(lds + r * 64 + ((c ^ sw_of(r)) << 3)) = v;
+  }
+}
+
+// Row-wise operand fragment from LDS: lane (l&31) -> row, 8 consecutive columns ks*16 + 8*(l>>5)..
+__device__ inline bf16x8 frag_rows(const bf16raw* lds, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 31);
+  const int c = ks * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ sw_of(row)) << 3));
+}
+
+// Transposed operand fragment: A[i = column col0 + (l&31)][k] with k running over the 16 rows
+// row0..row0+15 in the permuted order {0-3, 8-11 | 4-7, 12-15} (lower | upper half-wave).
+__device__ inline bf16x8 frag_cols(const bf16raw* lds, int row0, int col0, int lane) {
+  const int r = row0 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int c = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + sw_off(r, c)));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + sw_off(r + 8, c)));
+  return u.v;
+}
+
+// Row-wise operand fragment straight from global memory (rows beyond nvalid read as zero).
+template <typename RowFn>
+__device__ inline bf16x8 frag_global(const bf16raw* base, long ld, int col0, int row, int nvalid, int ks, int lane, RowFn rowfn) {
+  union { bf16x8 v; uint4 u; } x;
+  x.u = make_uint4(0, 0, 0, 0);
+  if (row < nvalid) x.u = *reinterpret_cast<const uint4*>(base + rowfn(row) * ld + col0 + ks * 16 + 8 * (lane >> 5));
+  return x.v;
+}
+
+__device__ inline bf16x8 pack8(const float* f) {
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
+  return v;
+}
+__device__ inline float frag_dot(const bf16x8& a, const bf16x8& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
+  return s;
+}
+__device__ inline void zero16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+// row index (within a 32-row tile) that accumulator register r of this lane holds
+__device__ inline int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Store a [32 x 64] result held transposed (lane&31 = row, registers = 64 columns in two C tiles)
+__device__ inline void store_rows_T(bf16raw* dst_row, const f32x16 (&acc)[2], float mul, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = nt * 32 + 8 * g + 4 * (lane >> 5);
+      uint2 w;
+      w.x = (uint32_t)f2bf(acc[nt][4 * g] * mul) | ((uint32_t)f2bf(acc[nt][4 * g + 1] * mul) << 16);
+      w.y = (uint32_t)f2bf(acc[nt][4 * g + 2] * mul) | ((uint32_t)f2bf(acc[nt][4 * g + 3] * mul) << 16);
+      *reinterpret_cast<uint2*>(dst_row + col) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(MA_THREADS) void attn_fwd_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+                                                                   bf16raw* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
+  bf16raw* Vs = Ks + Lp * 64;
+  auto rowfn = [&](int i) { return m_in_row(p, s, i); };
+  fill_tile(Ks, Lp, p.L, qkv, p.ld_qkv, D + h * 64, rowfn);
+  fill_tile(Vs, Lp, p.L, qkv, p.ld_qkv, 2 * D + h * 64, rowfn);
+  __syncthreads();
+  const float c2 = p.scale * LOG2E;
+  for (int qt = wave; qt < nt; qt += 4) {
+    const int q = qt * 32 + (lane & 31);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, q, p.L, ks, lane, rowfn);
+    f32x16 st[MA_MAXT];
+#pragma unroll
+    for (int kt = 0; kt < MA_MAXT; ++kt) {
+      zero16(st[kt]);
+      if (kt < nt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32, ks, lane), qf[ks], st[kt], 0, 0, 0);
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MA_MAXT; ++kt)
+      if (kt < nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + crow(r, lane);
+          const float v = key < p.L ? st[kt][r] * c2 : -INFINITY;
+          st[kt][r] = v;
+          m = fmaxf(m, v);
+        }
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < MA_MAXT; ++kt)
+      if (kt < nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(st[kt][r] - m); st[kt][r] = e; l += e; }
+      }
+    l += __shfl_xor(l, 32, 64);
+    f32x16 acc[2];
+    zero16(acc[0]);
+    zero16(acc[1]);
+#pragma unroll
+    for (int kt = 0; kt < MA_MAXT; ++kt)
+      if (kt < nt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float pf[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = st[kt][8 * s2 + j];
+          const bf16x8 pb = pack8(pf);
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+            acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, kt * 32 + 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
+        }
+      }
+    if (q < p.L) {
+      store_rows_T(out + m_out_row(p, s, q) * p.ld_out + h * 64, acc, 1.0f / l, lane);
+      if (lane < 32) lse[((long)s * p.H + h) * p.L + q] = m * LN2 + __logf(l);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- backward: dq
+__global__ __launch_bounds__(MA_THREADS) void attn_bwd_dq_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+                                                                      const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
+                                                                      const float* __restrict__ lse, float* __restrict__ delta,
+                                                                      bf16raw* __restrict__ dqkv, bf16raw* __restrict__ dqkv_cls) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
+  bf16raw* Vs = Ks + Lp * 64;
+  auto rin = [&](int i) { return m_in_row(p, s, i); };
+  auto rout = [&](int i) { return m_out_row(p, s, i); };
+  fill_tile(Ks, Lp, p.L, qkv, p.ld_qkv, D + h * 64, rin);
+  fill_tile(Vs, Lp, p.L, qkv, p.ld_qkv, 2 * D + h * 64, rin);
+  __syncthreads();
+  const float c2 = p.scale * LOG2E;
+  for (int qt = wave; qt < nt; qt += 4) {
+    const int q = qt * 32 + (lane & 31);
+    bf16x8 qf[4], df[4];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, q, p.L, ks, lane, rin);
+      df[ks] = frag_global(dout, p.ld_dout, h * 64, q, p.L, ks, lane, rout);
+      dl += frag_dot(df[ks], frag_global(o, p.ld_out, h * 64, q, p.L, ks, lane, rout));
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const long li = ((long)s * p.H + h) * p.L + q;
+    float l2 = 0.f;
+    if (q < p.L) {
+      l2 = lse[li] * LOG2E;
+      if (lane < 32) delta[li] = dl;
+    }
+    f32x16 acc[2];
+    zero16(acc[0]);
+    zero16(acc[1]);
+    for (int kt = 0; kt < nt; ++kt) {
+      f32x16 st, dp;
+      zero16(st);
+      zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32, ks, lane), qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kt * 32, ks, lane), df[ks], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + crow(r, lane);
+        const float pr = key < p.L ? __builtin_amdgcn_exp2f(st[r] * c2 - l2) : 0.f;
+        ds[r] = pr * (dp[r] - dl) * p.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 db = pack8(ds + 8 * s2);
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+          acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Ks, kt * 32 + 16 * s2, n2 * 32, lane), db, acc[n2], 0, 0, 0);
+      }
+    }
+    if (q < p.L) {
+      bf16raw* dst = (p.mode == VTX_ATTN_SPACE && q == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
+                                                          : dqkv + m_in_row(p, s, q) * p.ld_dqkv + h * 64;
+      store_rows_T(dst, acc, 1.0f, lane);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------- backward: dk, dv
+__global__ __launch_bounds__(MA_THREADS) void attn_bwd_dkv_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+                                                                       const bf16raw* __restrict__ dout, const float* __restrict__ lse,
+                                                                       const float* __restrict__ delta, bf16raw* __restrict__ dqkv,
+                                                                       bf16raw* __restrict__ dqkv_cls) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  bf16raw* Qs = reinterpret_cast<bf16raw*>(sm_raw);
+  bf16raw* Os = Qs + Lp * 64;
+  float* Ls = reinterpret_cast<float*>(Os + Lp * 64);   // lse * log2(e), +huge on padded rows
+  float* Ds = Ls + Lp;
+  auto rin = [&](int i) { return m_in_row(p, s, i); };
+  auto rout = [&](int i) { return m_out_row(p, s, i); };
+  fill_tile(Qs, Lp, p.L, qkv, p.ld_qkv, h * 64, rin);
+  fill_tile(Os, Lp, p.L, dout, p.ld_dout, h * 64, rout);
+  for (int i = threadIdx.x; i < Lp; i += MA_THREADS) {
+    const long li = ((long)s * p.H + h) * p.L + i;
+    Ls[i] = i < p.L ? lse[li] * LOG2E : 1e30f;
+    Ds[i] = i < p.L ? delta[li] : 0.f;
+  }
+  __syncthreads();
+  const float c2 = p.scale * LOG2E;
+  for (int kt = wave; kt < nt; kt += 4) {
+    const int key = kt * 32 + (lane & 31);
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_global(qkv, p.ld_qkv, D + h * 64, key, p.L, ks, lane, rin);
+      vf[ks] = frag_global(qkv, p.ld_qkv, 2 * D + h * 64, key, p.L, ks, lane, rin);
+    }
+    f32x16 dk[2], dv[2];
+    zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+    for (int qt = 0; qt < nt; ++qt) {
+      f32x16 st, dp;
+      zero16(st);
+      zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qt * 32, ks, lane), kf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Os, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qrow = qt * 32 + 8 * g + 4 * (lane >> 5);
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls + qrow);
+        const float4 d4 = *reinterpret_cast<const float4*>(Ds + qrow);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const float e = __builtin_amdgcn_exp2f(st[r] * c2 - lv[j]);
+          pr[r] = e;
+          ds[r] = e * (dp[r] - dvv[j]) * p.scale;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pb = pack8(pr + 8 * s2);
+        const bf16x8 db = pack8(ds + 8 * s2);
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Os, qt * 32 + 16 * s2, n2 * 32, lane), pb, dv[n2], 0, 0, 0);
+          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qs, qt * 32 + 16 * s2, n2 * 32, lane), db, dk[n2], 0, 0, 0);
+        }
+      }
+    }
+    if (key < p.L) {
+      bf16raw* base = (p.mode == VTX_ATTN_SPACE && key == 0) ? dqkv_cls + (long)s * p.ld_dqkv
+                                                             : dqkv + m_in_row(p, s, key) * p.ld_dqkv;
+      store_rows_T(base + D + h * 64, dk, 1.0f, lane);
+      store_rows_T(base + 2 * D + h * 64, dv, 1.0f, lane);
+    }
+  }
+}
+
+// host-side launchers used by attn.hip's entry points --------------------------------------
+bool attn_mfma_eligible(int dtype, int L, int hd) {
+  return dtype == VTX_BF16 && hd == 64 && L > 32 && L <= 32 * MA_MAXT;
+}
+
+int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
+  const int Lp = ((p.L + 31) >> 5) * 32;
+  const size_t lds = (size_t)2 * Lp * 64 * 2;
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv, (bf16raw*)out, lse);
+  return check_launch("attn_fwd_mfma");
+}
+
+int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
+                         float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
+  const int Lp = ((p.L + 31) >> 5) * 32;
+  const size_t lds = (size_t)2 * Lp * 64 * 2;
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv,
+                     (const bf16raw*)o, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
+  int rc = check_launch("attn_bwd_dq_mfma");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds + (size_t)2 * Lp * 4, st, p,
+                     (const bf16raw*)qkv, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
+  return check_launch("attn_bwd_dkv_mfma");
+}
+
+}  // namespace vtx
