@@ -106,6 +106,8 @@ typedef struct {
   const void* B; long ldb; vtx_rowmap bmap;
   float* C; long ldc; int accumulate;
   void* workspace; size_t ws_bytes;
+  float* colsum; int colsum_accumulate; /* optional: colsum[n1] (+)= sum_m A[amap(m)][n1] (the bias gradient,
+                                           fused: A tiles are already on chip) */
 } vtx_gemm_tn_desc;
 size_t vtx_gemm_tn_workspace(int M, int N1, int N2);
 int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream);

@@ -177,6 +177,13 @@ def test_gemm_tn_rowmap_and_colsum(dtype):
     check(f'gemm_tn rowmap {dtype}', C.cpu(), ref, 2e-3)
     cs = ops.colsum(dev(X, dtype), B * N, D1, amap=tm)
     check(f'colsum rowmap {dtype}', cs.cpu(), q(X, dtype)[:, 1:].reshape(-1, D1).sum(0), 1e-3)
+    C2, cs2 = ops.gemm_tn(dev(X, dtype), dev(Y, dtype), B * N, D1, D2, amap=tm, want_colsum=True)
+    check(f'gemm_tn fused colsum {dtype}', cs2.cpu(), q(X, dtype)[:, 1:].reshape(-1, D1).sum(0), 1e-3)
+    check(f'gemm_tn with fused colsum {dtype}', C2.cpu(), ref, 2e-3)
+    A3, B3 = rnd(5000, 216, seed=7), rnd(5000, 768, seed=8)
+    C3, cs3 = ops.gemm_tn(dev(A3, dtype), dev(B3, dtype), 5000, 216, 768, want_colsum=True)
+    check(f'gemm_tn fused colsum N1 tail {dtype}', cs3.cpu(), q(A3, dtype).sum(0), 1e-3)
+    check(f'gemm_tn N1 tail {dtype}', C3.cpu(), q(A3, dtype).t() @ q(B3, dtype), 2e-3)
     big = rnd(5000, 2304, seed=3)
     cs = ops.colsum(dev(big, dtype), 5000, 2304)
     check(f'colsum big {dtype}', cs.cpu(), q(big, dtype).sum(0), 1e-3)
@@ -252,11 +259,13 @@ def test_attention_space_mode(dtype, B, T, P):
     check(f'attn space bwd {dtype}', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
 
 
-def test_attention_mfma_matches_valu(monkeypatch):
-    """The bf16 MFMA kernels and the VALU kernels are two implementations of the same op."""
+@pytest.mark.parametrize('S,L', [(3, 197), (37, 8), (5, 9), (7, 16), (4, 32), (3, 33), (1, 256), (9, 1), (6, 5)])
+def test_attention_mfma_matches_valu(S, L, monkeypatch):
+    """The bf16 MFMA kernels (packed short sequences / 33..256 tokens) and the VALU kernels are
+    two implementations of the same op."""
     from vtx import ops
     from vtx._lib import ATTN_CONTIG
-    S, L, H, hd = 3, 197, 3, 64
+    H, hd = 3, 64
     D = H * hd
     qkv = dev(rnd(S, L, 3 * D, seed=5) * 1.5, torch.bfloat16)
     do = dev(rnd(S, L, D, seed=6), torch.bfloat16)
@@ -269,9 +278,9 @@ def test_attention_mfma_matches_valu(monkeypatch):
         dqkv = torch.full((S, L, 3 * D), float('nan'), dtype=torch.bfloat16, device=DEV)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
         res[mode] = (o.float().cpu(), lse.cpu(), dqkv.float().cpu())
-    check('attn mfma vs valu out', res['0'][0], res['1'][0], 1e-2)
-    check('attn mfma vs valu lse', res['0'][1], res['1'][1], 1e-4)
-    check('attn mfma vs valu dqkv', res['0'][2], res['1'][2], 2e-2)
+    check(f'attn mfma vs valu out S={S} L={L}', res['0'][0], res['1'][0], 1e-2)
+    check(f'attn mfma vs valu lse S={S} L={L}', res['0'][1], res['1'][1], 1e-4)
+    check(f'attn mfma vs valu dqkv S={S} L={L}', res['0'][2], res['1'][2], 2e-2)
 
 
 # ----------------------------------------------------------------------------- glue ops

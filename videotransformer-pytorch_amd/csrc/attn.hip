@@ -304,6 +304,12 @@ static bool use_mfma(int dtype, int L, int hd) {
   return attn_mfma_eligible(dtype, L, hd);
 }
 
+static bool use_small(int dtype, int mode, int L, int hd) {
+  const char* e = getenv("VTX_ATTN_VALU");
+  if (e && atoi(e) != 0) return false;
+  return attn_small_eligible(dtype, mode, L, hd);
+}
+
 static int make_params(const vtx_attn_desc* d, AttnP& p, const char* who) {
   VTX_REQUIRE(d->S > 0 && d->L > 0 && d->H > 0, VTX_EINVAL, "%s: bad shape S=%d L=%d H=%d", who, d->S, d->L, d->H);
   VTX_REQUIRE(d->hd == 64, VTX_EINVAL, "%s: head_dim %d unsupported (64 only)", who, d->hd);
@@ -344,7 +350,9 @@ extern "C" int vtx_attn_fwd(const vtx_attn_desc* d, void* stream) {
   hipStream_t st = as_stream(stream);
   const dim3 grid = attn_grid(p), block = attn_block(p);
   const size_t lds = attn_lds(p, 64, false);
-  if (use_mfma(d->dtype, d->L, d->hd)) {
+  if (use_small(d->dtype, d->mode, d->L, d->hd)) {
+    rc = attn_fwd_small_launch(p, d->qkv, d->out, d->lse, st);
+  } else if (use_mfma(d->dtype, d->L, d->hd)) {
     rc = attn_fwd_mfma_launch(p, d->qkv, d->out, d->lse, st);
   } else {
     if (d->dtype == VTX_F32)
@@ -373,6 +381,8 @@ extern "C" int vtx_attn_bwd(const vtx_attn_bwd_desc* d, void* stream) {
   hipStream_t st = as_stream(stream);
   const dim3 grid = attn_grid(p), block = attn_block(p);
   const size_t lds_a = attn_lds(p, 64, false), lds_b = attn_lds(p, 64, true);
+  if (use_small(d->f.dtype, d->f.mode, d->f.L, d->f.hd))
+    return attn_bwd_small_launch(p, d->f.qkv, d->f.out, d->dout, d->f.lse, d->dqkv, st);
   if (use_mfma(d->f.dtype, d->f.L, d->f.hd))
     return attn_bwd_mfma_launch(p, d->f.qkv, d->f.out, d->dout, d->f.lse, d->delta, d->dqkv, d->dqkv_cls, st);
   if (d->f.dtype == VTX_F32) {

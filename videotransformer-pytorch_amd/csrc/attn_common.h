@@ -25,6 +25,10 @@ __device__ inline long out_row(const AttnP& p, int s, int i) {
 
 // attn_mfma.hip
 bool attn_mfma_eligible(int dtype, int L, int hd);
+bool attn_small_eligible(int dtype, int mode, int L, int hd);
+int attn_fwd_small_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st);
+int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                          hipStream_t st);
 int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st);
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st);

@@ -335,9 +335,238 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_dkv_mfma_kernel(AttnP p, 
   }
 }
 
+// =====================================================================================
+// Short sequences (L <= 32, contiguous rows): temporal attention of the divided block
+// (L = T = 8) and ViViT's temporal encoder (L = 9).  G = 32/L sequences are packed into one
+// 32-row MFMA tile (block-diagonal mask); ONE WAVE handles a (tile, head) pair end to end, with
+// operands loaded straight from HBM into MFMA fragments (the row-wise fragment pattern covers
+// the [32][64] tile exactly once) and a wave-private 4 KB LDS tile per transposed operand.
+// HBM-bound: forward moves 4 and backward 8 row-blocks of [rows][64] per head.
+// =====================================================================================
+constexpr int SM_WAVE_LDS_FWD = 32 * 64 * 2;                   // V tile
+constexpr int SM_WAVE_LDS_BWD = 3 * 32 * 64 * 2 + 2 * 32 * 4;   // K, Q, dO tiles + lse + delta
+
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ inline void put_tile(bf16raw* lds, const bf16x8 (&f)[4], int lane) {
+  const int row = lane & 31;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = ks * 2 + (lane >> 5);
+    *reinterpret_cast<bf16x8*>(lds + row * 64 + ((c ^ sw_of(row)) << 3)) = f[ks];
+  }
+}
+__device__ inline void load_frags(bf16x8 (&f)[4], const bf16raw* base, long ld, int col0, long row, bool valid, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    union { bf16x8 v; uint4 u; } x;
+    x.u = make_uint4(0, 0, 0, 0);
+    if (valid) x.u = *reinterpret_cast<const uint4*>(base + row * ld + col0 + ks * 16 + 8 * (lane >> 5));
+    f[ks] = x.v;
+  }
+}
+
+__global__ __launch_bounds__(MA_THREADS) void attn_fwd_small_kernel(AttnP p, int ntiles, const bf16raw* __restrict__ qkv,
+                                                                    bf16raw* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave, h = blockIdx.y, D = p.H * 64;
+  if (tile >= ntiles) return;
+  bf16raw* Vs = reinterpret_cast<bf16raw*>(sm_raw + wave * SM_WAVE_LDS_FWD);
+  const int L = p.L, G = 32 / L, used = G * L;
+  const long row0 = (long)tile * used, total = (long)p.S * L;
+  const int i = lane & 31;
+  const bool valid = i < used && row0 + i < total;
+  bf16x8 qf[4], kf[4], vf[4];
+  load_frags(qf, qkv, p.ld_qkv, h * 64, row0 + i, valid, lane);
+  load_frags(kf, qkv, p.ld_qkv, D + h * 64, row0 + i, valid, lane);
+  load_frags(vf, qkv, p.ld_qkv, 2 * D + h * 64, row0 + i, valid, lane);
+  put_tile(Vs, vf, lane);
+  f32x16 st;
+  zero16(st);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+  const float c2 = p.scale * LOG2E;
+  const int qseq = i / L;
+  float m = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = crow(r, lane);
+    const bool ok = valid && key < used && key / L == qseq && row0 + key < total;
+    st[r] = ok ? st[r] * c2 : -INFINITY;
+    m = fmaxf(m, st[r]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (!valid) m = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m); l += st[r]; }
+  l += __shfl_xor(l, 32, 64);
+  wave_lds_sync();
+  f32x16 acc[2];
+  zero16(acc[0]);
+  zero16(acc[1]);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    float pf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = st[8 * s2 + j];
+    const bf16x8 pb = pack8(pf);
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+      acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
+  }
+  if (valid) {
+    store_rows_T(out + (row0 + i) * p.ld_out + h * 64, acc, 1.0f / l, lane);
+    if (lane < 32) {
+      const long sq = (row0 + i) / L;
+      lse[(sq * p.H + h) * L + (row0 + i - sq * L)] = m * LN2 + __logf(l);
+    }
+  }
+}
+
+__global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int ntiles, const bf16raw* __restrict__ qkv,
+                                                                    const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
+                                                                    const float* __restrict__ lse, bf16raw* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave, h = blockIdx.y, D = p.H * 64;
+  if (tile >= ntiles) return;
+  char* wl = sm_raw + wave * SM_WAVE_LDS_BWD;
+  bf16raw* Ks = reinterpret_cast<bf16raw*>(wl);
+  bf16raw* Qs = Ks + 32 * 64;
+  bf16raw* Os = Qs + 32 * 64;
+  float* Ls = reinterpret_cast<float*>(Os + 32 * 64);
+  float* Ds = Ls + 32;
+  const int L = p.L, G = 32 / L, used = G * L;
+  const long row0 = (long)tile * used, total = (long)p.S * L;
+  const int i = lane & 31;
+  const bool valid = i < used && row0 + i < total;
+  bf16x8 qf[4], kf[4], vf[4], df[4];
+  load_frags(qf, qkv, p.ld_qkv, h * 64, row0 + i, valid, lane);
+  load_frags(kf, qkv, p.ld_qkv, D + h * 64, row0 + i, valid, lane);
+  load_frags(vf, qkv, p.ld_qkv, 2 * D + h * 64, row0 + i, valid, lane);
+  load_frags(df, dout, p.ld_dout, h * 64, row0 + i, valid, lane);
+  float dl = 0.f;
+  {
+    bf16x8 of[4];
+    load_frags(of, o, p.ld_out, h * 64, row0 + i, valid, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dl += frag_dot(df[ks], of[ks]);
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  float l2 = 1e30f;
+  if (valid) {
+    const long sq = (row0 + i) / L;
+    l2 = lse[(sq * p.H + h) * L + (row0 + i - sq * L)] * LOG2E;
+  }
+  put_tile(Ks, kf, lane);
+  put_tile(Qs, qf, lane);
+  put_tile(Os, df, lane);
+  if (lane < 32) { Ls[i] = l2; Ds[i] = dl; }
+  const float c2 = p.scale * LOG2E;
+  const int myseq = i / L;
+  // ---- phase 1: lanes = queries.  dQ^T = K^T dS^T
+  {
+    f32x16 st, dp;
+    zero16(st);
+    zero16(dp);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], df[ks], dp, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = crow(r, lane);
+      const bool ok = valid && key < used && key / L == myseq && row0 + key < total;
+      const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - l2) : 0.f;
+      ds[r] = pr * (dp[r] - dl) * p.scale;
+    }
+    wave_lds_sync();
+    f32x16 acc[2];
+    zero16(acc[0]);
+    zero16(acc[1]);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 db = pack8(ds + 8 * s2);
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+        acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Ks, 16 * s2, n2 * 32, lane), db, acc[n2], 0, 0, 0);
+    }
+    if (valid) store_rows_T(dqkv + (row0 + i) * p.ld_dqkv + h * 64, acc, 1.0f, lane);
+  }
+  // ---- phase 2: lanes = keys.  dV^T = dO^T P, dK^T = Q^T dS
+  {
+    f32x16 st, dp;
+    zero16(st);
+    zero16(dp);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], vf[ks], dp, 0, 0, 0);
+    }
+    float pr[16], ds[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int qrow = 8 * g + 4 * (lane >> 5);
+      const float4 l4 = *reinterpret_cast<const float4*>(Ls + qrow);
+      const float4 d4 = *reinterpret_cast<const float4*>(Ds + qrow);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j;
+        const int q = qrow + j;
+        const bool ok = valid && q < used && q / L == myseq;
+        const float e = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lv[j]) : 0.f;
+        pr[r] = e;
+        ds[r] = e * (dp[r] - dvv[j]) * p.scale;
+      }
+    }
+    f32x16 dk[2], dv[2];
+    zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pb = pack8(pr + 8 * s2);
+      const bf16x8 db = pack8(ds + 8 * s2);
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Os, 16 * s2, n2 * 32, lane), pb, dv[n2], 0, 0, 0);
+        dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qs, 16 * s2, n2 * 32, lane), db, dk[n2], 0, 0, 0);
+      }
+    }
+    if (valid) {
+      bf16raw* base = dqkv + (row0 + i) * p.ld_dqkv;
+      store_rows_T(base + D + h * 64, dk, 1.0f, lane);
+      store_rows_T(base + 2 * D + h * 64, dv, 1.0f, lane);
+    }
+  }
+}
+
 // host-side launchers used by attn.hip's entry points --------------------------------------
 bool attn_mfma_eligible(int dtype, int L, int hd) {
   return dtype == VTX_BF16 && hd == 64 && L > 32 && L <= 32 * MA_MAXT;
+}
+bool attn_small_eligible(int dtype, int mode, int L, int hd) {
+  return dtype == VTX_BF16 && hd == 64 && mode == VTX_ATTN_CONTIG && L >= 1 && L <= 32;
+}
+int attn_fwd_small_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
+  const int G = 32 / p.L;
+  const int ntiles = (p.S + G - 1) / G;
+  hipLaunchKernelGGL(attn_fwd_small_kernel, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_FWD, st, p, ntiles,
+                     (const bf16raw*)qkv, (bf16raw*)out, lse);
+  return check_launch("attn_fwd_small");
+}
+int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                          hipStream_t st) {
+  const int G = 32 / p.L;
+  const int ntiles = (p.S + G - 1) / G;
+  hipLaunchKernelGGL(attn_bwd_small_kernel, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_BWD, st, p, ntiles,
+                     (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv);
+  return check_launch("attn_bwd_small");
 }
 
 int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {

@@ -33,6 +33,7 @@ constexpr int TN_LD32 = 128;
 struct TnOut {
   float* slab; long slab_stride;  // [splits][N1*N2]
   int N1, N2;
+  float* cslab;                   // [splits][N1] column sums of A (bias gradient), or nullptr
 };
 
 __device__ inline void tn_store(const TnOut& o, const float* stage, int split, int r_base, int c_base, int lane) {
@@ -112,9 +113,22 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_kernel(
   const int sf_row = 8 * (lane >> 5);           // SAFE path: own column, 8 rows
   const int sf_col = lane & 31;
 
+  const bool do_cs = out.cslab != nullptr && t2 == 0;     // block-uniform
+  float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TN_GLOAD16(m_begin);
   for (int mt = m_begin; mt < m_end; mt += TN_BKM) {
     TN_LSTORE16();
+    if (do_cs) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const uint32_t w[4] = {ra[it].x, ra[it].y, ra[it].z, ra[it].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          csum[2 * j] += __uint_as_float(w[j] << 16);
+          csum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+    }
     __syncthreads();
     if (mt + TN_BKM < m_end) TN_GLOAD16(mt + TN_BKM);
 #pragma unroll
@@ -145,6 +159,19 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (do_cs) {           // reduce the 16 row-lanes of every column chunk through LDS
+    float* red = reinterpret_cast<float*>(smem);            // [16][128]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[lr * 128 + lc * 8 + j] = csum[j];
+    __syncthreads();
+    if (tid < 128 && r0 + tid < out.N1) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += red[r * 128 + tid];
+      out.cslab[(long)split * out.N1 + r0 + tid] = a;
     }
     __syncthreads();
   }
@@ -209,9 +236,15 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_f32_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int kh = lane >> 5, col = lane & 31;
+  const bool do_cs = out.cslab != nullptr && t2 == 0;
+  float csum[4] = {0, 0, 0, 0};
   TN_GLOAD32(m_begin);
   for (int mt = m_begin; mt < m_end; mt += TN_BKM32) {
     TN_LSTORE32();
+    if (do_cs) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) { csum[0] += ra[it].x; csum[1] += ra[it].y; csum[2] += ra[it].z; csum[3] += ra[it].w; }
+    }
     __syncthreads();
     if (mt + TN_BKM32 < m_end) TN_GLOAD32(mt + TN_BKM32);
 #pragma unroll
@@ -227,6 +260,19 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_f32_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (do_cs) {
+    float* red = reinterpret_cast<float*>(smem);            // [8][128]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[lr * 128 + lc * 4 + j] = csum[j];
+    __syncthreads();
+    if (tid < 128 && r0 + tid < out.N1) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a += red[r * 128 + tid];
+      out.cslab[(long)split * out.N1 + r0 + tid] = a;
     }
     __syncthreads();
   }
@@ -287,7 +333,8 @@ static int colsum_blocks(int M) {
 using namespace vtx;
 
 extern "C" size_t vtx_gemm_tn_workspace(int M, int N1, int N2) {
-  return (size_t)tn_splits(M, N1, N2) * (size_t)N1 * (size_t)N2 * sizeof(float);
+  const size_t s = (size_t)tn_splits(M, N1, N2);
+  return s * (size_t)N1 * (size_t)N2 * sizeof(float) + s * (size_t)N1 * sizeof(float);   // slabs + column-sum slabs
 }
 
 extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
@@ -309,6 +356,7 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   const int tiles1 = cdiv(d->N1, 128), tiles2 = cdiv(d->N2, 128);
   TnOut out;
   out.slab = (float*)d->workspace; out.slab_stride = (long)d->N1 * d->N2; out.N1 = d->N1; out.N2 = d->N2;
+  out.cslab = d->colsum ? out.slab + (size_t)splits * out.slab_stride : nullptr;
   dim3 grid(tiles1 * tiles2 * splits), block(NT_THREADS);
   hipStream_t st = as_stream(stream);
   if (d->dtype == VTX_BF16) {
@@ -330,7 +378,9 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   }
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  return launch_reduce_partials(out.slab, splits, out.slab_stride, out.slab_stride, d->C, d->accumulate, 1.0f, st);
+  rc = launch_reduce_partials(out.slab, splits, out.slab_stride, out.slab_stride, d->C, d->accumulate, 1.0f, st);
+  if (rc || !d->colsum) return rc;
+  return launch_reduce_partials(out.cslab, splits, d->N1, d->N1, d->colsum, d->colsum_accumulate, 1.0f, st);
 }
 
 extern "C" size_t vtx_colsum_workspace(int M, int N) {

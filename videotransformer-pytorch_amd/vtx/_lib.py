@@ -46,6 +46,7 @@ class GemmTnDesc(C.Structure):
         ('B', C.c_void_p), ('ldb', C.c_long), ('bmap', RowMap),
         ('C', C.c_void_p), ('ldc', C.c_long), ('accumulate', C.c_int),
         ('workspace', C.c_void_p), ('ws_bytes', C.c_size_t),
+        ('colsum', C.c_void_p), ('colsum_accumulate', C.c_int),
     ]
 
 

@@ -97,22 +97,19 @@ class TimeAttnFn(torch.autograd.Function):
         tm = ops.tokmap(N)
         dtp = x.dtype
         # temporal_fc
-        d_tfc_w = ops.gemm_tn(dout, a, M, D, D, amap=tm)
-        d_tfc_b = ops.colsum(dout, M, D, amap=tm)
+        d_tfc_w, d_tfc_b = ops.gemm_tn(dout, a, M, D, D, amap=tm, want_colsum=True)
         _, wtT = weights(tfc_w, dtp, True)
         da = _empty((M, D), x)
         ops.gemm_nt(dout, wtT, da, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
         # proj
-        d_proj_w = ops.gemm_tn(da, o, M, D, D)
-        d_proj_b = ops.colsum(da, M, D)
+        d_proj_w, d_proj_b = ops.gemm_tn(da, o, M, D, D, want_colsum=True)
         _, wpT = weights(proj_w, dtp, True)
         do = _empty((M, D), x)
         ops.gemm_nt(da, wpT, do, M, D, D)
         # attention core
         dqkv = _empty((M, 3 * D), x)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, T, heads, hd, hd ** -0.5)
-        d_qkv_w = ops.gemm_tn(dqkv, xn, M, 3 * D, D)
-        d_qkv_b = ops.colsum(dqkv, M, 3 * D)
+        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M, 3 * D, D, want_colsum=True)
         _, wqT = weights(qkv_w, dtp, True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
@@ -183,8 +180,7 @@ class SpaceAttnFn(torch.autograd.Function):
         dtp = x.dtype
         da = _empty((Mo, D), x)
         ops.space_grad_prep(dout, sv, da, B, T, P, D)
-        d_proj_w = ops.gemm_tn(da, o, Mo, D, D)
-        d_proj_b = ops.colsum(da, Mo, D)
+        d_proj_w, d_proj_b = ops.gemm_tn(da, o, Mo, D, D, want_colsum=True)
         _, wpT = weights(proj_w, dtp, True)
         do = _empty((Mo, D), x)
         ops.gemm_nt(da, wpT, do, Mo, D, D)
@@ -193,8 +189,7 @@ class SpaceAttnFn(torch.autograd.Function):
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_SPACE, B * T, P + 1, heads, hd, hd ** -0.5, B, T, P,
                      dqkv_cls=dqkv_cls)
         ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, N1)
-        d_qkv_w = ops.gemm_tn(dqkv, xn, M1, 3 * D, D)
-        d_qkv_b = ops.colsum(dqkv, M1, 3 * D)
+        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M1, 3 * D, D, want_colsum=True)
         _, wqT = weights(qkv_w, dtp, True)
         dxn = _empty((M1, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M1, D, 3 * D)
@@ -252,15 +247,13 @@ class SelfAttnFn(torch.autograd.Function):
             ops.row_scale_copy(dout, da, M, D, s=sv, rs=(L, 1, 1, 0))
         else:
             da = dout
-        d_proj_w = ops.gemm_tn(da, o, M, D, D)
-        d_proj_b = ops.colsum(da, M, D)
+        d_proj_w, d_proj_b = ops.gemm_tn(da, o, M, D, D, want_colsum=True)
         _, wpT = weights(proj_w, dtp, True)
         do = _empty((M, D), x)
         ops.gemm_nt(da, wpT, do, M, D, D)
         dqkv = _empty((M, 3 * D), x)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, Bn, L, heads, hd, hd ** -0.5)
-        d_qkv_w = ops.gemm_tn(dqkv, xn, M, 3 * D, D)
-        d_qkv_b = ops.colsum(dqkv, M, 3 * D)
+        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M, 3 * D, D, want_colsum=True)
         _, wqT = weights(qkv_w, dtp, True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
@@ -312,13 +305,11 @@ class FFNFn(torch.autograd.Function):
             ops.row_scale_copy(dout, dz, M, D, s=sv, rs=(rows_per, 1, 1, 0))
         else:
             dz = dout
-        d_w2 = ops.gemm_tn(dz, g, M, D, Hd)
-        d_b2 = ops.colsum(dz, M, D)
+        d_w2, d_b2 = ops.gemm_tn(dz, g, M, D, Hd, want_colsum=True)
         _, w2T = weights(w2, dtp, True)
         dh = _empty((M, Hd), x)
         ops.gemm_nt(dz, w2T, dh, M, Hd, D, dgelu_in=h)
-        d_w1 = ops.gemm_tn(dh, xn, M, Hd, D)
-        d_b1 = ops.colsum(dh, M, Hd)
+        d_w1, d_b1 = ops.gemm_tn(dh, xn, M, Hd, D, want_colsum=True)
         _, w1T = weights(w1, dtp, True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dh, w1T, dxn, M, D, Hd)
@@ -424,8 +415,8 @@ class PatchEmbedFn(torch.autograd.Function):
         (rows,) = ctx.saved_tensors
         M, D, K, w_shape = ctx.cfg
         dy = _chk(dy).reshape(M, D)
-        d_w = ops.gemm_tn(dy, rows, M, D, K).reshape(w_shape)
-        d_b = ops.colsum(dy, M, D)
+        d_w, d_b = ops.gemm_tn(dy, rows, M, D, K, want_colsum=True)
+        d_w = d_w.reshape(w_shape)
         return None, d_w, d_b, None
 
 
@@ -489,8 +480,10 @@ class LinearFn(torch.autograd.Function):
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
-        d_w = ops.gemm_tn(dy, x, M, N, K)
-        d_b = ops.colsum(dy, M, N) if ctx.has_bias else None
+        if ctx.has_bias:
+            d_w, d_b = ops.gemm_tn(dy, x, M, N, K, want_colsum=True)
+        else:
+            d_w, d_b = ops.gemm_tn(dy, x, M, N, K), None
         _, wT = weights(w, x.dtype, True)
         dx = torch.empty_like(x)
         ops.gemm_nt(dy, wT, dx, M, K, N)
