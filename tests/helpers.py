@@ -14,7 +14,11 @@ REPORT = os.path.join(ROOT, 'gpurun_out', 'parity_report.txt')
 # (a bf16 autocast CPU run of the reference itself deviates by 8.6e-3).
 TOL_F32 = 1e-3
 TOL_BF16 = 3e-2
-TOL_BF16_GRAD = 6e-2
+# bf16 parameter gradients after 12 layers of bf16 backward (bf16 P / dS operands in the attention
+# MFMAs, bf16 activation gradients): bar on the relative L2 error; single elements may deviate by
+# up to 2.5x that (checked too).
+TOL_BF16_GRAD = 4e-2
+ELEMENT_SLACK = 2.5
 
 
 def gold(name):
@@ -47,28 +51,41 @@ def check(name, got, ref, tol):
     return e
 
 
-def compare_grads(prefix, named_grads, g, tol, tol_norm=None):
-    """named_grads: {param_name: grad tensor}; g: golden npz from make_golden.grads_summary."""
-    worst = 0.0
+def l2err(a, b):
+    a = torch.as_tensor(np.asarray(a)).double() if not torch.is_tensor(a) else a.detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-30)
+
+
+def compare_grads(prefix, named_grads, g, tol, exact_elements=False):
+    """named_grads: {param_name: grad tensor}; g: golden npz from make_golden.grads_summary.
+    fp32 path (exact_elements): every element within tol of max|ref| (the 1e-3 bar).
+    bf16 path: relative L2 error <= tol and every element within ELEMENT_SLACK*tol of max|ref|."""
+    worst_l2 = worst_max = 0.0
     n = 0
     for k in g.files:
         if k.startswith('g:'):
-            e = relerr(named_grads[k[2:]], g[k])
+            got, ref = named_grads[k[2:]].detach().double().cpu(), torch.as_tensor(g[k]).double()
+            scale = ref.abs().max().item()
+            norm_err = 0.0
         elif k.startswith('gh:'):
             name = k[3:]
             gn = g['gn:' + name]
-            got = named_grads[name].detach().double().cpu()
-            # head of the tensor relative to the tensor's rms, plus norm / sum checks
-            rms = gn[0] / (got.numel() ** 0.5)
-            e = (got.flatten()[:256] - torch.as_tensor(g[k]).double()).abs().max().item() / max(
-                torch.as_tensor(g[k]).abs().max().item(), rms, 1e-30)
-            e = max(e, abs(got.norm().item() - gn[0]) / max(gn[0], 1e-30))
+            full = named_grads[name].detach().double().cpu()
+            got, ref = full.flatten()[:256], torch.as_tensor(g[k]).double()
+            # the stored head of a large tensor: scale by the larger of its own max and the tensor's rms
+            scale = max(ref.abs().max().item(), gn[0] / (full.numel() ** 0.5))
+            norm_err = abs(full.norm().item() - gn[0]) / max(gn[0], 1e-30)
         else:
             continue
+        e_max = (got - ref).abs().max().item() / max(scale, 1e-30)
+        e_l2 = max((got - ref).norm().item() / max(ref.norm().item(), 1e-30), norm_err)
         n += 1
-        worst = max(worst, e)
-        if e > tol:
-            report(f'FAIL {prefix} grad {k}: rel={e:.3e}')
-        assert e <= tol, f'{prefix}: grad {k} rel err {e:.3e} > {tol:g}'
-    report(f'ok   {prefix}: {n} parameter gradients, worst rel={worst:.3e} (tol {tol:g})')
-    return worst
+        worst_l2, worst_max = max(worst_l2, e_l2), max(worst_max, e_max)
+        lim_max = tol if exact_elements else ELEMENT_SLACK * tol
+        bad = e_max > lim_max or (not exact_elements and e_l2 > tol)
+        if bad:
+            report(f'FAIL {prefix} grad {k}: max-rel={e_max:.3e} l2-rel={e_l2:.3e}')
+        assert not bad, f'{prefix}: grad {k} max-rel {e_max:.3e} l2-rel {e_l2:.3e} (tol {tol:g})'
+    report(f'ok   {prefix}: {n} parameter gradients, worst max-rel={worst_max:.3e} l2-rel={worst_l2:.3e} (tol {tol:g})')
+    return worst_max

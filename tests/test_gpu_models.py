@@ -1,8 +1,8 @@
 """Model-level parity of the HIP path (through the drop-in nn.Module API and the C ABI)
 against (a) the committed golden vectors generated from the reference and (b) the CPU oracle.
 
-Bars (tests/helpers.py): fp32 path 1e-3 relative (north_star); bf16 path 3e-2 on outputs and
-6e-2 on parameter gradients versus the same fp32 reference (a bf16-autocast CPU run of the
+Bars (tests/helpers.py): fp32 path 1e-3 relative (north_star); bf16 path 3e-2 on outputs and, on
+parameter gradients, 4e-2 relative L2 (single elements up to 2.5x that) versus the same fp32 reference (a bf16-autocast CPU run of the
 reference itself deviates by 8.6e-3 after 12 layers).
 All weights come from oracle/synth.py: temporal_fc is NOT zero, so the temporal kernels matter.
 """
@@ -59,7 +59,7 @@ def test_timesformer_small_vs_golden(at, prec, tol, gtol):
     y, grads = _train_step(m, x, 11, 128)
     assert y.dtype == torch.float32 and y.shape == (3, 128)
     check(f'tsf_small {at} {prec} train out', y.cpu(), g['out'], tol)
-    compare_grads(f'tsf_small {at} {prec}', grads, g, gtol)
+    compare_grads(f'tsf_small {at} {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
     m.eval()
     with torch.no_grad():
         check(f'tsf_small {at} {prec} eval out', m(x.to(DEV)).cpu(), g['out_eval'], tol)
@@ -80,7 +80,7 @@ def test_vivit_small_vs_golden(at, prec, tol, gtol):
     x = synth.synth_clip(3, 8, 3, 64, 64, seed=5)
     y, grads = _train_step(m, x, 13, 128)
     check(f'vivit_small {at} {prec} train out', y.cpu(), g['out'], tol)
-    compare_grads(f'vivit_small {at} {prec}', grads, g, gtol)
+    compare_grads(f'vivit_small {at} {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
@@ -106,7 +106,7 @@ def test_timesformer_b_t8_train_vs_golden(prec, tol, gtol):
     m, _ = _build(V.TimeSformer, 0, num_frames=8)
     y, grads = _train_step(m, synth.synth_clip(1, 8, seed=1), 7, 768)
     check(f'TimeSformer-B T=8 train {prec} out', y.cpu(), g['out'], tol)
-    compare_grads(f'TimeSformer-B T=8 train {prec}', grads, g, gtol)
+    compare_grads(f'TimeSformer-B T=8 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
     ge = gold('tsf_b_t8_eval.npz')
     m.eval()
     with torch.no_grad():
