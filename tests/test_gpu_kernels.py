@@ -82,10 +82,16 @@ def test_layernorm_fwd_bwd(dtype, D):
 
 
 # --------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('nodma', ['0', '1'])
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1568, 2304, 768), (130, 216, 768), (257, 768, 96), (64, 8, 8)])
-def test_gemm_nt_plain(dtype, M, N, K):
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1568, 2304, 768), (130, 216, 768), (257, 768, 96), (64, 8, 8),
+                                   (12544, 768, 3072)])
+def test_gemm_nt_plain(dtype, M, N, K, nodma, monkeypatch):
+    """nodma=0: LDS-DMA staged kernel when K % 64 == 0 (bf16); nodma=1: register-staged kernel."""
     from vtx import ops
+    if nodma == '1' and dtype == torch.float32:
+        pytest.skip('fp32 has a single kernel')
+    monkeypatch.setenv('VTX_GEMM_NODMA', nodma)
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
     ref = q(A, dtype) @ q(W, dtype).t() + b.double()
     C = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
@@ -150,16 +156,19 @@ def test_gemm_nt_epilogues(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304)])
+@pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304), (12552, 768, 768)])
 def test_gemm_tn(dtype, M, N1, N2, monkeypatch):
     from vtx import ops
     A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
     ref = q(A, dtype).t() @ q(Bm, dtype)
-    for safe in (['0', '1'] if dtype == torch.bfloat16 else ['0']):
+    for safe, nodma in ([('0', '0'), ('0', '1'), ('1', '1')] if dtype == torch.bfloat16 else [('0', '0')]):
         monkeypatch.setenv('VTX_TN_SAFE', safe)
-        C = ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2)
-        check(f'gemm_tn {dtype} safe={safe} {M}x{N1}x{N2}', C.cpu(), ref, 2e-3 if dtype == torch.bfloat16 else 1e-3)
+        monkeypatch.setenv('VTX_GEMM_NODMA', nodma)
+        C, cs = ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2, want_colsum=True)
+        check(f'gemm_tn {dtype} safe={safe} nodma={nodma} {M}x{N1}x{N2}', C.cpu(), ref, 2e-3 if dtype == torch.bfloat16 else 1e-3)
+        check(f'gemm_tn colsum {dtype} safe={safe} nodma={nodma} {M}x{N1}x{N2}', cs.cpu(), q(A, dtype).sum(0), 1e-3)
     monkeypatch.setenv('VTX_TN_SAFE', '0')
+    monkeypatch.setenv('VTX_GEMM_NODMA', '0')
     C0 = torch.ones(N1, N2, device=DEV)
     ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2, out=C0, accumulate=True)
     check(f'gemm_tn accumulate {dtype}', C0.cpu(), ref + 1, 2e-3)

@@ -2,7 +2,7 @@
 against (a) the committed golden vectors generated from the reference and (b) the CPU oracle.
 
 Bars (tests/helpers.py): fp32 path 1e-3 relative (north_star); bf16 path 3e-2 on outputs and, on
-parameter gradients, 4e-2 relative L2 (single elements up to 2.5x that) versus the same fp32 reference (a bf16-autocast CPU run of the
+parameter gradients, 8e-2 relative L2 (calibration in tests/helpers.py) versus the same fp32 reference (a bf16-autocast CPU run of the
 reference itself deviates by 8.6e-3 after 12 layers).
 All weights come from oracle/synth.py: temporal_fc is NOT zero, so the temporal kernels matter.
 """

@@ -93,6 +93,9 @@ __device__ inline float gelu_erf_grad(float x) {
 // ---- host-side error plumbing --------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// out[n] (+)= scale * sum_s part[s*stride + n]; columns >= split optionally go to out2 (ln.hip)
+int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out, int accumulate, float scale,
+                           hipStream_t st, float* out2 = nullptr, long split = 0, int accumulate2 = 0);
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define VTX_REQUIRE(cond, code, ...)        \

@@ -17,6 +17,7 @@
 // fused bias / GELU / GELU' / DropPath-scale / residual / row-scatter run on
 // row-contiguous 8-element vectors, independent of the MFMA register layout.
 // Algorithmic FLOPs per launch: 2*M*N*K.
+#include <stdlib.h>
 #include "gemm_common.h"
 
 namespace vtx {
@@ -124,6 +125,101 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_kernel(
   float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
   stage_acc(stage, acc, lane);
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private staging, no barrier needed
+  __builtin_amdgcn_wave_barrier();
+  epilogue<bf16raw>(ep, stage, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------- bf16 kernel, LDS-DMA staging
+// Same tile / fragment / epilogue code as above, but the operand tiles go HBM -> LDS directly
+// with global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  A wave-instruction lands
+// 64 x 16 B = 1 KiB = 8 tile rows at a wave-uniform LDS base in lane order, so the XOR swizzle
+// is applied on the SOURCE side: lane (row, physical chunk pc) fetches logical chunk
+// pc ^ ((row>>1)&7) of its row -- still one full 128-B line per 8 lanes.  Requires K % 64 == 0.
+__device__ inline void dma16(const bf16raw* src, bf16raw* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_dma_kernel(
+    int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][128][64]
+  bf16raw* Bs = As + 2 * BM * BK16;                                  // [2][128][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging assignment: wave w issues pieces j = 0..3 of each operand; piece p = w*4+j covers
+  // tile rows [8p, 8p+8): lane -> row 8p + (lane>>3), physical chunk lane&7
+  const bf16raw* ap[4];
+  const bf16raw* bp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int ma = m0 + row; if (ma >= M) ma = M - 1;
+    int nb = n0 + row; if (nb >= N) nb = N - 1;
+    ap[j] = A + map_row(amap, ma) * lda + c * 8;
+    bp[j] = B + (long)nb * ldb + c * 8;
+  }
+#define STAGE_DMA(buf_, k0_)                                                     \
+  {                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                              \
+      dma16(ap[j] + (k0_), As + (buf_) * BM * BK16 + (wave * 4 + j) * 8 * BK16); \
+      dma16(bp[j] + (k0_), Bs + (buf_) * BN * BK16 + (wave * 4 + j) * 8 * BK16); \
+    }                                                                            \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int a_row_off[2], b_row_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ar = wm * 64 + i * 32 + (lane & 31);
+    const int br = wn * 64 + i * 32 + (lane & 31);
+    a_row_off[i] = ar * BK16; a_sw[i] = (ar >> 1) & 7;
+    b_row_off[i] = br * BK16; b_sw[i] = (br >> 1) & 7;
+  }
+  const int khalf = lane >> 5;
+  const int nk = K / BK16;
+  STAGE_DMA(0, 0);
+  __syncthreads();                         // carries the vmcnt(0) for the LDS-DMA
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) STAGE_DMA(buf ^ 1, (kt + 1) * BK16);
+    const bf16raw* Ab = As + buf * BM * BK16;
+    const bf16raw* Bb = Bs + buf * BN * BK16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + khalf;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row_off[i] + ((c ^ a_sw[i]) << 3));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(Bb + b_row_off[i] + ((c ^ b_sw[i]) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#undef STAGE_DMA
+  float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stage, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   epilogue<bf16raw>(ep, stage, m0 + wm * 64, n0 + wn * 64, lane);
 }
@@ -265,8 +361,13 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   hipStream_t st = as_stream(stream);
   if (d->dtype == VTX_BF16) {
     const size_t lds = STAGE_BYTES > 4 * BM * BK16 * 2 ? STAGE_BYTES : 4 * BM * BK16 * 2;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
-                       d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
+    const char* nodma = getenv("VTX_GEMM_NODMA");
+    if (d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0))
+      hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
+                         d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
+    else
+      hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
+                         d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
   } else {
     const size_t need = (size_t)4 * BM * LD32 * 4;
     const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;

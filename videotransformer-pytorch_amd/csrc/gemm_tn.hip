@@ -22,9 +22,6 @@
 
 namespace vtx {
 
-int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
-                           int accumulate, float scale, hipStream_t st);
-
 constexpr int TN_BKM = 64;        // m rows per tile (bf16)
 constexpr int TN_LD = 160;        // padded row length (bf16 elements)
 constexpr int TN_BKM32 = 16;      // m rows per tile (fp32)
@@ -171,7 +168,161 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_kernel(
       float a = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a += red[r * 128 + tid];
-      out.cslab[(long)split * out.N1 + r0 + tid] = a;
+      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
+    }
+    __syncthreads();
+  }
+  float* stage = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stage, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  tn_store(out, stage, split, r0 + wm * 64, c0 + wn * 64, lane);
+}
+
+// ---- bf16 with LDS-DMA staging -----------------------------------------------------------
+// Tiles [64 m][128 n] bf16, 256-B rows, no padding (a DMA piece = 1 KiB = 4 whole rows).  The
+// 16-B chunk index is XOR-ed with (row&3)<<2 on the SOURCE side so the 4 rows x 64 B a half-wave
+// touches in one ds_read_b64_tr_b16 fall into the four different 64-B bank quarters.  Full
+// 64-row tiles are staged by DMA into a double buffer; the (at most one) ragged last tile of a
+// split goes through registers with zero fill.
+__device__ inline void tn_dma16(const bf16raw* src, bf16raw* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+constexpr int TN_DLD = 128;   // elements per LDS row in the DMA layout
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_dma_kernel(
+    int M, int m_per_split, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* As = reinterpret_cast<bf16raw*>(smem);          // [2][64][128]
+  bf16raw* Bs = As + 2 * TN_BKM * TN_DLD;                  // [2][64][128]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x / tiles12;
+  const int tile = blockIdx.x - split * tiles12;
+  const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+  const int r0 = t1 * 128, c0 = t2 * 128;
+  const int m_begin = split * m_per_split;
+  const int m_end = min(M, m_begin + m_per_split);
+
+  // DMA assignment: piece p = wave*4 + j covers tile rows 4p..4p+3; lane -> row 4p + (lane>>4), physical chunk lane&15
+  const int prow = lane >> 4;                               // == row & 3
+  const int lchunk = (lane & 15) ^ (prow << 2);             // logical chunk this lane fetches
+  const int a_col = (r0 + lchunk * 8) < out.N1 ? r0 + lchunk * 8 : 0;   // out-of-range columns: any valid address
+  const int b_col = (c0 + lchunk * 8) < out.N2 ? c0 + lchunk * 8 : 0;
+#define TN_STAGE_DMA(buf_, mt_)                                                                       \
+  {                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+      const int m = (mt_) + (wave * 4 + j) * 4 + prow;                                                \
+      tn_dma16(A + map_row(amap, m) * lda + a_col, As + (buf_) * TN_BKM * TN_DLD + (wave * 4 + j) * 4 * TN_DLD); \
+      tn_dma16(B + map_row(bmap, m) * ldb + b_col, Bs + (buf_) * TN_BKM * TN_DLD + (wave * 4 + j) * 4 * TN_DLD); \
+    }                                                                                                 \
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed fragment addressing (see gemm_tn_bf16_kernel); row&3 == (lane&15)>>2 for both reads
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_sw = ((lane & 15) >> 2) << 2;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = wm * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int cb = wn * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    a_off[i] = tr_row * TN_DLD + (((ca >> 3) ^ tr_sw) << 3) + (ca & 7);
+    b_off[i] = tr_row * TN_DLD + (((cb >> 3) ^ tr_sw) << 3) + (cb & 7);
+  }
+  // column sums of A (bias gradient): thread owns logical chunk cs_chunk of rows (tid>>4) + 16*it
+  const bool do_cs = out.cslab != nullptr && t2 == 0;
+  const int cs_row = tid >> 4;
+  const int cs_pc = tid & 15;
+  const int cs_chunk = cs_pc ^ ((cs_row & 3) << 2);
+  float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int n_full = (m_end - m_begin) > 0 ? (m_end - m_begin) / TN_BKM : 0;
+  const int rem = (m_end - m_begin) > 0 ? (m_end - m_begin) - n_full * TN_BKM : 0;
+  const int n_tiles = n_full + (rem ? 1 : 0);
+  // ragged tile loader (registers, zero fill): thread -> row tid>>4 + 16*it, physical chunk tid&15
+  auto stage_ragged = [&](int buf, int mt) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = (tid >> 4) + 16 * it;
+      const int m = mt + row;
+      const int lc = (tid & 15) ^ ((row & 3) << 2);
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        if (r0 + lc * 8 < out.N1) va = *reinterpret_cast<const uint4*>(A + map_row(amap, m) * lda + r0 + lc * 8);
+        if (c0 + lc * 8 < out.N2) vb = *reinterpret_cast<const uint4*>(B + map_row(bmap, m) * ldb + c0 + lc * 8);
+      }
+      *reinterpret_cast<uint4*>(As + buf * TN_BKM * TN_DLD + row * TN_DLD + (tid & 15) * 8) = va;
+      *reinterpret_cast<uint4*>(Bs + buf * TN_BKM * TN_DLD + row * TN_DLD + (tid & 15) * 8) = vb;
+    }
+  };
+  if (n_tiles > 0) {
+    if (n_full > 0) { TN_STAGE_DMA(0, m_begin); } else { stage_ragged(0, m_begin); }
+  }
+  __syncthreads();
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int buf = ti & 1;
+    if (ti + 1 < n_tiles) {
+      const int mt = m_begin + (ti + 1) * TN_BKM;
+      if (ti + 1 < n_full) { TN_STAGE_DMA(buf ^ 1, mt); } else { stage_ragged(buf ^ 1, mt); }
+    }
+    const bf16raw* Ab = As + buf * TN_BKM * TN_DLD;
+    const bf16raw* Bb = Bs + buf * TN_BKM * TN_DLD;
+    if (do_cs) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const uint4 v = *reinterpret_cast<const uint4*>(Ab + (cs_row + 16 * it) * TN_DLD + cs_pc * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          csum[2 * j] += __uint_as_float(w[j] << 16);
+          csum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < TN_BKM / 16; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16raw* pa = Ab + ks * 16 * TN_DLD + a_off[i];
+        const bf16raw* pb = Bb + ks * 16 * TN_DLD + b_off[i];
+        union { bf16x8 v; s16x4 h[2]; } ua, ub;
+        ua.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+        ua.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * TN_DLD));
+        ub.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+        ub.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * TN_DLD));
+        af[i] = ua.v; bfr[i] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#undef TN_STAGE_DMA
+  if (do_cs) {
+    float* red = reinterpret_cast<float*>(smem);            // [16][128]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[cs_row * 128 + cs_chunk * 8 + j] = csum[j];
+    __syncthreads();
+    if (tid < 128 && r0 + tid < out.N1) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += red[r * 128 + tid];
+      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
     }
     __syncthreads();
   }
@@ -272,7 +423,7 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_f32_kernel(
       float a = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) a += red[r * 128 + tid];
-      out.cslab[(long)split * out.N1 + r0 + tid] = a;
+      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
     }
     __syncthreads();
   }
@@ -355,8 +506,10 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   m_per = cdiv(m_per, tile_m) * tile_m;
   const int tiles1 = cdiv(d->N1, 128), tiles2 = cdiv(d->N2, 128);
   TnOut out;
-  out.slab = (float*)d->workspace; out.slab_stride = (long)d->N1 * d->N2; out.N1 = d->N1; out.N2 = d->N2;
-  out.cslab = d->colsum ? out.slab + (size_t)splits * out.slab_stride : nullptr;
+  // per-split slab = [N1*N2 weight partials | N1 column-sum partials]
+  const long w_elems = (long)d->N1 * d->N2;
+  out.slab = (float*)d->workspace; out.slab_stride = w_elems + d->N1; out.N1 = d->N1; out.N2 = d->N2;
+  out.cslab = d->colsum ? out.slab + w_elems : nullptr;
   dim3 grid(tiles1 * tiles2 * splits), block(NT_THREADS);
   hipStream_t st = as_stream(stream);
   if (d->dtype == VTX_BF16) {
@@ -364,7 +517,13 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;
     const char* safe_env = getenv("VTX_TN_SAFE");   // diagnostic path, read per call
     const bool safe = safe_env && atoi(safe_env) != 0;
-    if (safe)
+    const char* nodma = getenv("VTX_GEMM_NODMA");
+    if (!safe && !(nodma && atoi(nodma) != 0)) {
+      const size_t need_d = (size_t)4 * TN_BKM * TN_DLD * 2;
+      const size_t lds_d = STAGE_BYTES > need_d ? STAGE_BYTES : need_d;
+      hipLaunchKernelGGL(gemm_tn_bf16_dma_kernel, grid, block, lds_d, st, d->M, m_per, (const bf16raw*)d->A, d->lda,
+                         d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1 * tiles2, out);
+    } else if (safe)
       hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, block, lds, st, d->M, m_per, (const bf16raw*)d->A, d->lda,
                          d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1 * tiles2, out);
     else
@@ -378,9 +537,9 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   }
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  rc = launch_reduce_partials(out.slab, splits, out.slab_stride, out.slab_stride, d->C, d->accumulate, 1.0f, st);
-  if (rc || !d->colsum) return rc;
-  return launch_reduce_partials(out.cslab, splits, d->N1, d->N1, d->colsum, d->colsum_accumulate, 1.0f, st);
+  if (!d->colsum) return launch_reduce_partials(out.slab, splits, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
+  return launch_reduce_partials(out.slab, splits, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
+                                d->colsum, w_elems, d->colsum_accumulate);
 }
 
 extern "C" size_t vtx_colsum_workspace(int M, int N) {

@@ -178,8 +178,10 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(
 
 // out[n] (+)= scale * sum_s part[s*stride + n], n < N.  64 columns x 4 slab lanes per block:
 // coalesced 256-B row segments, independent loads in flight, fixed summation order.
+// Columns n >= split (when out2 != nullptr) go to out2[n - split] (two results, one launch).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nslabs, long stride,
-                                                              long N, float* __restrict__ out, int accumulate, float scale) {
+                                                              long N, float* __restrict__ out, int accumulate, float scale,
+                                                              float* __restrict__ out2, long split, int accumulate2) {
   __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
   const long n = (long)blockIdx.x * 64 + cx;
@@ -198,14 +200,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   __syncthreads();
   if (sy == 0 && n < N) {
     const float a = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * scale;
-    out[n] = accumulate ? out[n] + a : a;
+    if (out2 != nullptr && n >= split) {
+      float* o = out2 + (n - split);
+      *o = accumulate2 ? *o + a : a;
+    } else {
+      out[n] = accumulate ? out[n] + a : a;
+    }
   }
 }
 
 int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
-                           int accumulate, float scale, hipStream_t st) {
+                           int accumulate, float scale, hipStream_t st, float* out2, long split, int accumulate2) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, part, nslabs,
-                     stride, N, out, accumulate, scale);
+                     stride, N, out, accumulate, scale, out2, split, accumulate2);
   return check_launch("reduce_partials");
 }
 
@@ -309,8 +316,6 @@ extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, lon
   else
     VTX_REQUIRE(false, VTX_EINVAL, "layernorm_bwd: bad dtype %d", dtype);
   if (rc) return rc;
-  // part layout: [block][2][D] -> dgamma = sum_b part[b][0], dbeta = sum_b part[b][1]
-  rc = launch_reduce_partials(part, nb, 2L * D, D, dgamma, 1, 1.0f, st);
-  if (rc) return rc;
-  return launch_reduce_partials(part + D, nb, 2L * D, D, dbeta, 1, 1.0f, st);
+  // part layout: [block][2][D] -> dgamma += sum_b part[b][0], dbeta += sum_b part[b][1] (one launch)
+  return launch_reduce_partials(part, nb, 2L * D, 2L * D, dgamma, 1, 1.0f, st, dbeta, D, 1);
 }

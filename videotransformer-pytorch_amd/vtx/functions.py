@@ -19,9 +19,11 @@ def weights(p, dtype, need_t=None):
     """(W, W^T) copies of Linear weight ``p`` [out,in] in ``dtype``; cached until p changes."""
     if need_t is None:
         need_t = torch.is_grad_enabled()
-    key = (id(p), dtype)
+    # keyed by storage address, not id(): ctx.saved_tensors hands back NEW tensor objects that
+    # share the parameter's storage and version counter
+    key = (p.data_ptr(), tuple(p.shape), dtype)
     hit = _wcache.get(key)
-    ver = (p._version, p.data_ptr())
+    ver = p._version
     if hit is not None and hit[0] == ver and (hit[2] is not None or not need_t):
         return hit[1], hit[2]
     w2d = p.detach().reshape(p.shape[0], -1)
