@@ -82,6 +82,19 @@ def test_layernorm_fwd_bwd(dtype, D):
 
 
 # --------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('variant', ['ring256x3', 'ring128x3', 'ring128x4', 'dma2'])
+def test_gemm_nt_bf16_variants(variant, monkeypatch):
+    """Every staging variant of the bf16 NT GEMM (2-buffer DMA, DMA rings with counted vmcnt)."""
+    from vtx import ops
+    monkeypatch.setenv('VTX_GEMM_NT', variant)
+    for (M, N, K) in [(1568, 2304, 768), (3000, 216, 3072), (1030, 768, 192), (12544, 768, 768)]:
+        A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
+        ref = q(A, torch.bfloat16) @ q(W, torch.bfloat16).t() + b.double()
+        C = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+        ops.gemm_nt(dev(A, torch.bfloat16), dev(W, torch.bfloat16), C, M, N, K, bias=dev(b))
+        check(f'gemm_nt {variant} {M}x{N}x{K}', C.float().cpu(), ref, 1e-2)
+
+
 @pytest.mark.parametrize('nodma', ['0', '1'])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1568, 2304, 768), (130, 216, 768), (257, 768, 96), (64, 8, 8),

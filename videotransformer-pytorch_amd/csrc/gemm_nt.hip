@@ -18,6 +18,7 @@
 // row-contiguous 8-element vectors, independent of the MFMA register layout.
 // Algorithmic FLOPs per launch: 2*M*N*K.
 #include <stdlib.h>
+#include <string>
 #include "gemm_common.h"
 
 namespace vtx {
@@ -224,6 +225,132 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_dma_kernel(
   epilogue<bf16raw>(ep, stage, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+// ------------------------------------------- bf16 kernel, LDS-DMA ring with counted vmcnt
+// (WM*64) x 128 output tile, WM x 2 waves (each 64x64), NBUF-deep ring of K tiles staged by
+// LDS-DMA.  Tile kt+NBUF-1 is issued while tile kt is consumed; a wave waits only for ITS OWN
+// oldest tile with a counted `s_waitcnt vmcnt(PW*(NBUF-2))` and the workgroup meets at ONE raw
+// s_barrier per K tile (no vmcnt(0) drain), so NBUF-1 tiles of HBM/L2 latency are in flight
+// per workgroup.  The measured per-tile cost of the 2-buffer kernel above is one full memory
+// latency (~1.2 us) per K tile -- this is the fix.
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int NBUF>
+__global__ __launch_bounds__(WM * 128) void gemm_nt_bf16_ring_kernel(
+    int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
+  constexpr int NW = WM * 2;                 // waves
+  constexpr int RBM = WM * 64;               // tile rows
+  constexpr int BPW = 16 / NW;               // B pieces per wave per stage (A: always 4)
+  constexpr int PW = 4 + BPW;                // DMA instructions per wave per stage
+  constexpr int STAGE_ELEMS = (RBM + BN) * BK16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* ring = reinterpret_cast<bf16raw*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * RBM, n0 = tn * BN;
+
+  const bf16raw* ap[4];
+  const bf16raw* bp[BPW];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int ma = m0 + row; if (ma >= M) ma = M - 1;
+    ap[j] = A + map_row(amap, ma) * lda + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int row = (wave * BPW + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int nb = n0 + row; if (nb >= N) nb = N - 1;
+    bp[j] = B + (long)nb * ldb + c * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    bf16raw* Ab = ring + buf * STAGE_ELEMS;
+    bf16raw* Bb = Ab + RBM * BK16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16(ap[j] + k0, Ab + (wave * 4 + j) * 8 * BK16);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) dma16(bp[j] + k0, Bb + (wave * BPW + j) * 8 * BK16);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_row_off[2], b_row_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ar = wm * 64 + i * 32 + (lane & 31);
+    const int br = wn * 64 + i * 32 + (lane & 31);
+    a_row_off[i] = ar * BK16; a_sw[i] = (ar >> 1) & 7;
+    b_row_off[i] = br * BK16; b_sw[i] = (br >> 1) & 7;
+  }
+  const int khalf = lane >> 5;
+  const int nk = K / BK16;
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s)
+    if (s < nk) stage(s, s * BK16);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NBUF - 2 < nk) wait_vmcnt<PW * (NBUF - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    {
+      const int nxt = kt + NBUF - 1;
+      int nbuf = buf + NBUF - 1; if (nbuf >= NBUF) nbuf -= NBUF;
+      if (nxt < nk) stage(nbuf, nxt * BK16);
+    }
+    const bf16raw* Ab = ring + buf * STAGE_ELEMS;
+    const bf16raw* Bb = Ab + RBM * BK16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + khalf;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row_off[i] + ((c ^ a_sw[i]) << 3));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(Bb + b_row_off[i] + ((c ^ b_sw[i]) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (++buf == NBUF) buf = 0;
+  }
+  __syncthreads();                              // every wave is done with the ring -> reuse it for staging
+  float* stg = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
+  stage_acc(stg, acc, lane);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  epilogue<bf16raw>(ep, stg, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+template <int WM, int NBUF>
+static int launch_ring(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st) {
+  constexpr int RBM = WM * 64;
+  const size_t ring_bytes = (size_t)NBUF * (RBM + BN) * BK16 * 2;
+  const size_t stage_bytes = (size_t)WM * 2 * 64 * STAGE_LD * 4;
+  const size_t lds = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_ring_kernel<WM, NBUF>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tiles_m = cdiv(d->M, RBM), tiles_n = cdiv(d->N, BN);
+  hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<WM, NBUF>), dim3(tiles_m * tiles_n), dim3(WM * 128), lds, st, d->M, d->N,
+                     d->K, (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
+  return check_launch("gemm_nt_ring");
+}
+
 // ------------------------------------------------------------------ fp32 kernel
 constexpr int BK32 = 16;
 constexpr int LD32 = BK32 + 1;
@@ -362,7 +489,13 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   if (d->dtype == VTX_BF16) {
     const size_t lds = STAGE_BYTES > 4 * BM * BK16 * 2 ? STAGE_BYTES : 4 * BM * BK16 * 2;
     const char* nodma = getenv("VTX_GEMM_NODMA");
-    if (d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0))
+    const char* kv = getenv("VTX_GEMM_NT");             // tuning override: dma2 | ring128x3 | ring128x4 | ring256x3
+    const bool dma_ok = d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0);
+    std::string variant = kv ? kv : (d->M >= 1024 ? "ring256x3" : "dma2");
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3") return launch_ring<4, 3>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring128x3") return launch_ring<2, 3>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 4 && variant == "ring128x4") return launch_ring<2, 4>(d, ep, st);
+    if (dma_ok)
       hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
                          d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
     else

@@ -7,6 +7,8 @@ video_transformer.py:228,236).  Parameters stay float32; their compute-dtype
 copies (and the transposes used by the input-gradient GEMMs) are staged by
 ``weights()`` and cached per parameter version.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -16,19 +18,23 @@ _wcache = {}
 
 
 def weights(p, dtype, need_t=None):
-    """(W, W^T) copies of Linear weight ``p`` [out,in] in ``dtype``; cached until p changes."""
+    """(W, W^T) copies of Linear weight ``p`` [out,in] in ``dtype``; cached on the parameter OBJECT
+    (weak reference) until its version counter moves.  Forward passes fetch both copies and hand
+    W^T to backward through ctx.save_for_backward (ctx.saved_tensors returns new tensor objects, and
+    storage addresses are recycled between models, so neither id() nor data_ptr() of a saved tensor
+    is a safe cache key)."""
     if need_t is None:
         need_t = torch.is_grad_enabled()
-    # keyed by storage address, not id(): ctx.saved_tensors hands back NEW tensor objects that
-    # share the parameter's storage and version counter
-    key = (p.data_ptr(), tuple(p.shape), dtype)
+    key = (id(p), dtype)
     hit = _wcache.get(key)
-    ver = p._version
-    if hit is not None and hit[0] == ver and (hit[2] is not None or not need_t):
-        return hit[1], hit[2]
+    if hit is not None and hit[0]() is p and hit[1] == p._version and (hit[3] is not None or not need_t):
+        return hit[2], hit[3]
     w2d = p.detach().reshape(p.shape[0], -1)
     wc, wt = ops.cast_transpose(w2d, dtype, want_c=True, want_t=need_t)
-    _wcache[key] = (ver, wc, wt)
+    if len(_wcache) > 4096:                       # dead parameters: drop stale entries
+        for k in [k for k, v in _wcache.items() if v[0]() is None]:
+            del _wcache[k]
+    _wcache[key] = (weakref.ref(p), p._version, wc, wt)
     return wc, wt
 
 
@@ -65,7 +71,7 @@ class TimeAttnFn(torch.autograd.Function):
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, _ = weights(qkv_w, dtp)
+        wq, wqT = weights(qkv_w, dtp)
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
         o = _empty((M, D), x)
@@ -73,21 +79,22 @@ class TimeAttnFn(torch.autograd.Function):
         lse = _empty((S * heads * T,), x, torch.float32)
         scale = hd ** -0.5
         ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, T, heads, hd, scale)
-        wp, _ = weights(proj_w, dtp)
+        wp, wpT = weights(proj_w, dtp)
         a = _empty((M, D), x)
         ops.gemm_nt(o, wp, a, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(T, 1, 1, 0))
-        wt, _ = weights(tfc_w, dtp)
+        wt, wtT = weights(tfc_w, dtp)
         out = torch.empty_like(x)
         ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=x, rmap=tm)
         ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        ctx.save_for_backward(x, ln_w, qkv_w, proj_w, tfc_w, mean, rstd, xn, qkv, o, lse, a,
-                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse, a,
+                              scale_vec if scale_vec is not None else x.new_empty(0),
+                              *[t for t in (wqT, wpT, wtT) if t is not None])
         ctx.cfg = (T, heads, scale_vec is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, ln_w, qkv_w, proj_w, tfc_w, mean, rstd, xn, qkv, o, lse, a, sv = ctx.saved_tensors
+        x, ln_w, mean, rstd, xn, qkv, o, lse, a, sv, wqT, wpT, wtT = ctx.saved_tensors
         T, heads, has_scale = ctx.cfg
         sv = sv if has_scale else None
         dout = _chk(dout)
@@ -100,19 +107,16 @@ class TimeAttnFn(torch.autograd.Function):
         dtp = x.dtype
         # temporal_fc
         d_tfc_w, d_tfc_b = ops.gemm_tn(dout, a, M, D, D, amap=tm, want_colsum=True)
-        _, wtT = weights(tfc_w, dtp, True)
         da = _empty((M, D), x)
         ops.gemm_nt(dout, wtT, da, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
         # proj
         d_proj_w, d_proj_b = ops.gemm_tn(da, o, M, D, D, want_colsum=True)
-        _, wpT = weights(proj_w, dtp, True)
         do = _empty((M, D), x)
         ops.gemm_nt(da, wpT, do, M, D, D)
         # attention core
         dqkv = _empty((M, 3 * D), x)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, T, heads, hd, hd ** -0.5)
         d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M, 3 * D, D, want_colsum=True)
-        _, wqT = weights(qkv_w, dtp, True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
         # LayerNorm + residual
@@ -143,7 +147,7 @@ class SpaceAttnFn(torch.autograd.Function):
         mean = _empty((M1,), x, torch.float32)
         rstd = _empty((M1,), x, torch.float32)
         ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, _ = weights(qkv_w, dtp)
+        wq, wqT = weights(qkv_w, dtp)
         qkv = _empty((M1, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M1, 3 * D, D, bias=qkv_b)
         Mo = B * N + B * T
@@ -155,21 +159,22 @@ class SpaceAttnFn(torch.autograd.Function):
         if want_probs:
             ctx.mark_non_differentiable(probs)
             return probs
-        wp, _ = weights(proj_w, dtp)
+        wp, wpT = weights(proj_w, dtp)
         out = torch.empty_like(x)
         a_cls = _empty((B * T, D), x)
         tm = ops.tokmap(N)
         ops.gemm_nt(o, wp, out, Mo, D, D, cmap=tm, bias=proj_b, row_scale=scale_vec, rs=(N, T, T, 1),
                     R=x, rmap=tm, split_row=B * N, Csplit=a_cls)
         ops.cls_mean_fwd(a_cls, x, out, B, T, D, N1)
-        ctx.save_for_backward(x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse,
-                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse,
+                              scale_vec if scale_vec is not None else x.new_empty(0),
+                              *[t for t in (wqT, wpT) if t is not None])
         ctx.cfg = (T, heads, scale_vec is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse, sv = ctx.saved_tensors
+        x, ln_w, mean, rstd, xn, qkv, o, lse, sv, wqT, wpT = ctx.saved_tensors
         T, heads, has_scale = ctx.cfg
         sv = sv if has_scale else None
         dout = _chk(dout)
@@ -183,7 +188,6 @@ class SpaceAttnFn(torch.autograd.Function):
         da = _empty((Mo, D), x)
         ops.space_grad_prep(dout, sv, da, B, T, P, D)
         d_proj_w, d_proj_b = ops.gemm_tn(da, o, Mo, D, D, want_colsum=True)
-        _, wpT = weights(proj_w, dtp, True)
         do = _empty((Mo, D), x)
         ops.gemm_nt(da, wpT, do, Mo, D, D)
         dqkv = _empty((M1, 3 * D), x)
@@ -192,7 +196,6 @@ class SpaceAttnFn(torch.autograd.Function):
                      dqkv_cls=dqkv_cls)
         ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, N1)
         d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M1, 3 * D, D, want_colsum=True)
-        _, wqT = weights(qkv_w, dtp, True)
         dxn = _empty((M1, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M1, D, 3 * D)
         dx = torch.empty_like(x)
@@ -217,7 +220,7 @@ class SelfAttnFn(torch.autograd.Function):
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, _ = weights(qkv_w, dtp)
+        wq, wqT = weights(qkv_w, dtp)
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
         o = _empty((M, D), x)
@@ -227,17 +230,18 @@ class SelfAttnFn(torch.autograd.Function):
         if want_probs:
             ctx.mark_non_differentiable(probs)
             return probs
-        wp, _ = weights(proj_w, dtp)
+        wp, wpT = weights(proj_w, dtp)
         out = torch.empty_like(x)
         ops.gemm_nt(o, wp, out, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(L, 1, 1, 0), R=x)
-        ctx.save_for_backward(x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse,
-                              scale_vec if scale_vec is not None else x.new_empty(0))
+        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse,
+                              scale_vec if scale_vec is not None else x.new_empty(0),
+                              *[t for t in (wqT, wpT) if t is not None])
         ctx.cfg = (heads, scale_vec is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, ln_w, qkv_w, proj_w, mean, rstd, xn, qkv, o, lse, sv = ctx.saved_tensors
+        x, ln_w, mean, rstd, xn, qkv, o, lse, sv, wqT, wpT = ctx.saved_tensors
         heads, has_scale = ctx.cfg
         dout = _chk(dout)
         Bn, L, D = x.shape
@@ -250,13 +254,11 @@ class SelfAttnFn(torch.autograd.Function):
         else:
             da = dout
         d_proj_w, d_proj_b = ops.gemm_tn(da, o, M, D, D, want_colsum=True)
-        _, wpT = weights(proj_w, dtp, True)
         do = _empty((M, D), x)
         ops.gemm_nt(da, wpT, do, M, D, D)
         dqkv = _empty((M, 3 * D), x)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, Bn, L, heads, hd, hd ** -0.5)
         d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M, 3 * D, D, want_colsum=True)
-        _, wqT = weights(qkv_w, dtp, True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
         dx = torch.empty_like(x)
@@ -281,26 +283,26 @@ class FFNFn(torch.autograd.Function):
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        w1c, _ = weights(w1, dtp)
+        w1c, w1T = weights(w1, dtp)
         h = _empty((M, Hd), x)
         g = _empty((M, Hd), x)
         ops.gemm_nt(xn, w1c, g, M, Hd, D, bias=b1, act=1, C2=h)
-        w2c, _ = weights(w2, dtp)
+        w2c, w2T = weights(w2, dtp)
         out = torch.empty_like(x)
         ops.gemm_nt(g, w2c, out, M, D, Hd, bias=b2, row_scale=scale_vec, rs=(rows_per, 1, 1, 0), R=x)
-        ctx.save_for_backward(x, ln_w, w1, w2, mean, rstd, xn, h, g,
-                              scale_vec if scale_vec is not None else x.new_empty(0))
-        ctx.cfg = (rows_per, scale_vec is not None)
+        ctx.save_for_backward(x, ln_w, mean, rstd, xn, h, g,
+                              scale_vec if scale_vec is not None else x.new_empty(0),
+                              *[t for t in (w1T, w2T) if t is not None])
+        ctx.cfg = (rows_per, scale_vec is not None, w1.shape[0])
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, ln_w, w1, w2, mean, rstd, xn, h, g, sv = ctx.saved_tensors
-        rows_per, has_scale = ctx.cfg
+        x, ln_w, mean, rstd, xn, h, g, sv, w1T, w2T = ctx.saved_tensors
+        rows_per, has_scale, Hd = ctx.cfg
         dout = _chk(dout)
         D = x.shape[-1]
         M = x.numel() // D
-        Hd = w1.shape[0]
         dtp = x.dtype
         if has_scale:
             dz = _empty((M, D), x)
@@ -308,11 +310,9 @@ class FFNFn(torch.autograd.Function):
         else:
             dz = dout
         d_w2, d_b2 = ops.gemm_tn(dz, g, M, D, Hd, want_colsum=True)
-        _, w2T = weights(w2, dtp, True)
         dh = _empty((M, Hd), x)
         ops.gemm_nt(dz, w2T, dh, M, Hd, D, dgelu_in=h)
         d_w1, d_b1 = ops.gemm_tn(dh, xn, M, Hd, D, want_colsum=True)
-        _, w1T = weights(w1, dtp, True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dh, w1T, dxn, M, D, Hd)
         dx = torch.empty_like(x)
@@ -468,25 +468,25 @@ class LinearFn(torch.autograd.Function):
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
-        wc, _ = weights(w, x.dtype)
+        wc, wT = weights(w, x.dtype)
         y = _empty(tuple(x.shape[:-1]) + (N,), x)
         ops.gemm_nt(x, wc, y, M, N, K, bias=b)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, *([wT] if wT is not None else []))
         ctx.has_bias = b is not None
+        ctx.N = N
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, wT = ctx.saved_tensors
         dy = _chk(dy)
         K = x.shape[-1]
         M = x.numel() // K
-        N = w.shape[0]
+        N = ctx.N
         if ctx.has_bias:
             d_w, d_b = ops.gemm_tn(dy, x, M, N, K, want_colsum=True)
         else:
             d_w, d_b = ops.gemm_tn(dy, x, M, N, K), None
-        _, wT = weights(w, x.dtype, True)
         dx = torch.empty_like(x)
         ops.gemm_nt(dy, wT, dx, M, K, N)
         return dx, d_w, d_b
