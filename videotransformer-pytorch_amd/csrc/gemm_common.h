@@ -96,4 +96,28 @@ __device__ inline void epilogue(const EpiParams& p, const float* stage, int m_ba
 }
 
 
+// One 64-deep K tile of the wave's 64x64 block: 4 k-steps x (2 A + 2 B fragment reads, 4 MFMAs),
+// with the fragment reads of step ks+1 issued BEFORE the MFMAs of step ks (register double
+// buffer) so LDS latency hides behind the matrix pipe instead of serialising with it.
+// Expects in scope: acc[2][2], a_row_off[2], a_sw[2], b_row_off[2], b_sw[2], khalf.
+#define VTX_LD_FRAGS_BF16(Ab_, Bb_, ks_, af_, bf_)                                                              \
+  {                                                                                                             \
+    const int c__ = (ks_) * 2 + khalf;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+      af_[i] = *reinterpret_cast<const bf16x8*>((Ab_) + a_row_off[i] + ((c__ ^ a_sw[i]) << 3));                 \
+      bf_[i] = *reinterpret_cast<const bf16x8*>((Bb_) + b_row_off[i] + ((c__ ^ b_sw[i]) << 3));                 \
+    }                                                                                                           \
+  }
+#define VTX_MMA_TILE_BF16(Ab_, Bb_)                                                                             \
+  {                                                                                                             \
+    bf16x8 fa__[2][2], fb__[2][2];                                                                              \
+    VTX_LD_FRAGS_BF16(Ab_, Bb_, 0, fa__[0], fb__[0]);                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                          \
+      if (ks < 3) VTX_LD_FRAGS_BF16(Ab_, Bb_, ks + 1, fa__[(ks + 1) & 1], fb__[(ks + 1) & 1]);                  \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa__[ks & 1][i], fb__[ks & 1][j], acc[i][j], 0, 0, 0); \
+    }                                                                                                           \
+  }
+
 }  // namespace vtx

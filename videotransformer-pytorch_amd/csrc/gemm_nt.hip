@@ -103,21 +103,7 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_kernel(
     if (kt + 1 < nk) GLOAD16((kt + 1) * BK16);
     const bf16raw* Ab = As + buf * BM * BK16;
     const bf16raw* Bb = Bs + buf * BN * BK16;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks * 2 + khalf;
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row_off[i] + ((c ^ a_sw[i]) << 3));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(Bb + b_row_off[i] + ((c ^ b_sw[i]) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    VTX_MMA_TILE_BF16(Ab, Bb);
     if (kt + 1 < nk) LSTORE16(buf ^ 1);
     __syncthreads();
   }
@@ -200,21 +186,7 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_dma_kernel(
     if (kt + 1 < nk) STAGE_DMA(buf ^ 1, (kt + 1) * BK16);
     const bf16raw* Ab = As + buf * BM * BK16;
     const bf16raw* Bb = Bs + buf * BN * BK16;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks * 2 + khalf;
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row_off[i] + ((c ^ a_sw[i]) << 3));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(Bb + b_row_off[i] + ((c ^ b_sw[i]) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    VTX_MMA_TILE_BF16(Ab, Bb);
     __syncthreads();
   }
 #undef STAGE_DMA
@@ -308,21 +280,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_bf16_ring_kernel(
     }
     const bf16raw* Ab = ring + buf * STAGE_ELEMS;
     const bf16raw* Bb = Ab + RBM * BK16;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks * 2 + khalf;
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row_off[i] + ((c ^ a_sw[i]) << 3));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(Bb + b_row_off[i] + ((c ^ b_sw[i]) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    VTX_MMA_TILE_BF16(Ab, Bb);
     if (++buf == NBUF) buf = 0;
   }
   __syncthreads();                              // every wave is done with the ring -> reuse it for staging

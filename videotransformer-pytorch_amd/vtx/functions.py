@@ -23,8 +23,8 @@ def weights(p, dtype, need_t=None):
     W^T to backward through ctx.save_for_backward (ctx.saved_tensors returns new tensor objects, and
     storage addresses are recycled between models, so neither id() nor data_ptr() of a saved tensor
     is a safe cache key)."""
-    if need_t is None:
-        need_t = torch.is_grad_enabled()
+    if need_t is None:          # NB: grad mode is off inside autograd.Function.forward -- callers there pass
+        need_t = torch.is_grad_enabled()   # any(ctx.needs_input_grad) explicitly
     key = (id(p), dtype)
     hit = _wcache.get(key)
     if hit is not None and hit[0]() is p and hit[1] == p._version and (hit[3] is not None or not need_t):
@@ -71,7 +71,7 @@ class TimeAttnFn(torch.autograd.Function):
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, wqT = weights(qkv_w, dtp)
+        wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
         o = _empty((M, D), x)
@@ -79,10 +79,10 @@ class TimeAttnFn(torch.autograd.Function):
         lse = _empty((S * heads * T,), x, torch.float32)
         scale = hd ** -0.5
         ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, T, heads, hd, scale)
-        wp, wpT = weights(proj_w, dtp)
+        wp, wpT = weights(proj_w, dtp, any(ctx.needs_input_grad))
         a = _empty((M, D), x)
         ops.gemm_nt(o, wp, a, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(T, 1, 1, 0))
-        wt, wtT = weights(tfc_w, dtp)
+        wt, wtT = weights(tfc_w, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
         ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=x, rmap=tm)
         ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
@@ -147,7 +147,7 @@ class SpaceAttnFn(torch.autograd.Function):
         mean = _empty((M1,), x, torch.float32)
         rstd = _empty((M1,), x, torch.float32)
         ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, wqT = weights(qkv_w, dtp)
+        wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M1, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M1, 3 * D, D, bias=qkv_b)
         Mo = B * N + B * T
@@ -159,7 +159,7 @@ class SpaceAttnFn(torch.autograd.Function):
         if want_probs:
             ctx.mark_non_differentiable(probs)
             return probs
-        wp, wpT = weights(proj_w, dtp)
+        wp, wpT = weights(proj_w, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
         a_cls = _empty((B * T, D), x)
         tm = ops.tokmap(N)
@@ -220,7 +220,7 @@ class SelfAttnFn(torch.autograd.Function):
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, wqT = weights(qkv_w, dtp)
+        wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
         o = _empty((M, D), x)
@@ -230,7 +230,7 @@ class SelfAttnFn(torch.autograd.Function):
         if want_probs:
             ctx.mark_non_differentiable(probs)
             return probs
-        wp, wpT = weights(proj_w, dtp)
+        wp, wpT = weights(proj_w, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
         ops.gemm_nt(o, wp, out, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(L, 1, 1, 0), R=x)
         ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse,
@@ -283,11 +283,11 @@ class FFNFn(torch.autograd.Function):
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        w1c, w1T = weights(w1, dtp)
+        w1c, w1T = weights(w1, dtp, any(ctx.needs_input_grad))
         h = _empty((M, Hd), x)
         g = _empty((M, Hd), x)
         ops.gemm_nt(xn, w1c, g, M, Hd, D, bias=b1, act=1, C2=h)
-        w2c, w2T = weights(w2, dtp)
+        w2c, w2T = weights(w2, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
         ops.gemm_nt(g, w2c, out, M, D, Hd, bias=b2, row_scale=scale_vec, rs=(rows_per, 1, 1, 0), R=x)
         ctx.save_for_backward(x, ln_w, mean, rstd, xn, h, g,
@@ -468,7 +468,7 @@ class LinearFn(torch.autograd.Function):
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
-        wc, wT = weights(w, x.dtype)
+        wc, wT = weights(w, x.dtype, any(ctx.needs_input_grad))
         y = _empty(tuple(x.shape[:-1]) + (N,), x)
         ops.gemm_nt(x, wc, y, M, N, K, bias=b)
         ctx.save_for_backward(x, *([wT] if wT is not None else []))
