@@ -70,6 +70,7 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False):
         if k.startswith('g:'):
             got, ref = named_grads[k[2:]].detach().double().cpu(), torch.as_tensor(g[k]).double()
             scale = ref.abs().max().item()
+            scale_rms = 0.0
             norm_err = 0.0
         elif k.startswith('gh:'):
             name = k[3:]
@@ -77,12 +78,16 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False):
             full = named_grads[name].detach().double().cpu()
             got, ref = full.flatten()[:256], torch.as_tensor(g[k]).double()
             # the stored head of a large tensor: scale by the larger of its own max and the tensor's rms
-            scale = max(ref.abs().max().item(), gn[0] / (full.numel() ** 0.5))
+            scale_rms = gn[0] / (full.numel() ** 0.5)
+            scale = max(ref.abs().max().item(), scale_rms)
             norm_err = abs(full.norm().item() - gn[0]) / max(gn[0], 1e-30)
         else:
             continue
         e_max = (got - ref).abs().max().item() / max(scale, 1e-30)
-        e_l2 = max((got - ref).norm().item() / max(ref.norm().item(), 1e-30), norm_err)
+        # L2 error relative to the larger of the compared slice's norm and the norm that many typical
+        # (rms-sized) elements of the tensor would have -- a 256-element head can be atypically small
+        ref_norm = max(ref.norm().item(), scale_rms * (ref.numel() ** 0.5))
+        e_l2 = max((got - ref).norm().item() / max(ref_norm, 1e-30), norm_err)
         n += 1
         worst_l2, worst_max = max(worst_l2, e_l2), max(worst_max, e_max)
         lim_max = tol if exact_elements else ELEMENT_SLACK * tol
