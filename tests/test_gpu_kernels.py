@@ -82,7 +82,7 @@ def test_layernorm_fwd_bwd(dtype, D):
 
 
 # --------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize('variant', ['ring256x3', 'ring128x3', 'ring128x4', 'dma2'])
+@pytest.mark.parametrize('variant', ['ring256x3', 'ring256x3k32', 'ring256x4k32', 'ring128x3', 'ring128x4k32', 'dma2'])
 def test_gemm_nt_bf16_variants(variant, monkeypatch):
     """Every staging variant of the bf16 NT GEMM (2-buffer DMA, DMA rings with counted vmcnt)."""
     from vtx import ops

@@ -39,7 +39,7 @@ def main():
                 continue
             A, W, C = r(M, K), r(Nn, K), torch.empty(M, Nn, device=DEV, dtype=dtype)
             bias = torch.randn(Nn, device=DEV)
-            for variant in (['dma2', 'ring128x3', 'ring128x4', 'ring256x3'] if dtype == torch.bfloat16 else ['-']):
+            for variant in (['dma2', 'ring128x4k32', 'ring256x3', 'ring256x3k32', 'ring256x4k32'] if dtype == torch.bfloat16 else ['-']):
                 os.environ['VTX_GEMM_NT'] = variant
                 t = timeit(lambda: ops.gemm_nt(A, W, C, M, Nn, K, bias=bias))
                 print(f'gemm_nt {name} {tag:5s} {variant:9s} M={M} N={Nn} K={K}: {t*1e6:8.1f} us  {2*M*Nn*K/t/1e12:7.1f} TFLOP/s', flush=True)

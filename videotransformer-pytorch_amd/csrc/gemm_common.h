@@ -44,10 +44,20 @@ __device__ inline void stage_acc(float* stage, const f32x16 (&acc)[2][2], int la
       }
 }
 
-template <typename T>
+// Half-tile variants (32 rows per pass): 8.7 KB of staging per wave instead of 17.4 KB, for kernels
+// whose LDS budget is sized for two co-resident workgroups per CU.
+__device__ inline void stage_acc_half(float* stage, const f32x16 (&acc)[2], int lane) {
+  const int col = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + rhalf) * STAGE_LD + ni * 32 + col] = acc[ni][r];
+}
+
+template <typename T, int ROWS = 64>
 __device__ inline void epilogue(const EpiParams& p, const float* stage, int m_base, int n_base, int lane) {
 #pragma unroll 1
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 0; e < ROWS / 8; ++e) {
     const int rw = e * 8 + (lane >> 3);
     const int m = m_base + rw;
     const int n = n_base + (lane & 7) * 8;

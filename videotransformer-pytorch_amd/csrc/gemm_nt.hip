@@ -198,23 +198,33 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_dma_kernel(
 }
 
 // ------------------------------------------- bf16 kernel, LDS-DMA ring with counted vmcnt
-// (WM*64) x 128 output tile, WM x 2 waves (each 64x64), NBUF-deep ring of K tiles staged by
-// LDS-DMA.  Tile kt+NBUF-1 is issued while tile kt is consumed; a wave waits only for ITS OWN
+// (WM*64) x 128 output tile, WM x 2 waves (each 64x64), NBUF-deep ring of BK-deep K tiles staged
+// by LDS-DMA.  Tile kt+NBUF-1 is issued while tile kt is consumed; a wave waits only for ITS OWN
 // oldest tile with a counted `s_waitcnt vmcnt(PW*(NBUF-2))` and the workgroup meets at ONE raw
-// s_barrier per K tile (no vmcnt(0) drain), so NBUF-1 tiles of HBM/L2 latency are in flight
-// per workgroup.  The measured per-tile cost of the 2-buffer kernel above is one full memory
-// latency (~1.2 us) per K tile -- this is the fix.
+// s_barrier per K tile (no vmcnt(0) drain), so NBUF-1 tiles of memory latency are in flight per
+// workgroup.  Measured on the 2-buffer kernel above: one full memory latency (~1.2 us) per K tile.
+//   <4,3,64>: 144 KB of LDS, one workgroup (8 waves) per CU.
+//   <4,3,32>:  72 KB, TWO workgroups per CU, so one's prologue / epilogue (measured ~8 us per
+//              tile, ~40 % of a K=768 tile) overlaps the other's main loop.
+// LDS rows are BK elements; 16-B chunk swizzle: BK=64 -> ^((row>>1)&7), BK=32 -> ^((row>>2)&3).
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int NBUF>
-__global__ __launch_bounds__(WM * 128) void gemm_nt_bf16_ring_kernel(
+template <int BK> __device__ inline int ring_sw(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+template <int WM, int NBUF, int BK>
+__global__ __launch_bounds__(WM * 128, (BK == 32 ? 1024 : 512) / (WM * 128) * (WM * 128) / 256) void gemm_nt_bf16_ring_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
   constexpr int NW = WM * 2;                 // waves
   constexpr int RBM = WM * 64;               // tile rows
-  constexpr int BPW = 16 / NW;               // B pieces per wave per stage (A: always 4)
-  constexpr int PW = 4 + BPW;                // DMA instructions per wave per stage
-  constexpr int STAGE_ELEMS = (RBM + BN) * BK16;
+  constexpr int RPP = 512 / BK;              // tile rows per 1-KiB DMA piece
+  constexpr int LPR = BK / 8;                // lanes (16-B chunks) per row
+  constexpr int APW = RBM / RPP / NW;        // A pieces per wave per stage
+  constexpr int BPW = BN / RPP / NW;         // B pieces per wave per stage
+  constexpr int PW = APW + BPW;              // DMA instructions per wave per stage
+  constexpr int KS = BK / 16;                // MFMA k-steps per stage
+  constexpr int STAGE_ELEMS = (RBM + BN) * BK;
+  static_assert(APW >= 1 && BPW >= 1, "tile too small for this many waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* ring = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -224,29 +234,29 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_bf16_ring_kernel(
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * RBM, n0 = tn * BN;
 
-  const bf16raw* ap[4];
+  const bf16raw* ap[APW];
   const bf16raw* bp[BPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+  for (int j = 0; j < APW; ++j) {
+    const int row = (wave * APW + j) * RPP + lane / LPR;
+    const int c = (lane % LPR) ^ ring_sw<BK>(row);
     int ma = m0 + row; if (ma >= M) ma = M - 1;
     ap[j] = A + map_row(amap, ma) * lda + c * 8;
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
-    const int row = (wave * BPW + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = (wave * BPW + j) * RPP + lane / LPR;
+    const int c = (lane % LPR) ^ ring_sw<BK>(row);
     int nb = n0 + row; if (nb >= N) nb = N - 1;
     bp[j] = B + (long)nb * ldb + c * 8;
   }
   auto stage = [&](int buf, int k0) {
     bf16raw* Ab = ring + buf * STAGE_ELEMS;
-    bf16raw* Bb = Ab + RBM * BK16;
+    bf16raw* Bb = Ab + RBM * BK;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma16(ap[j] + k0, Ab + (wave * 4 + j) * 8 * BK16);
+    for (int j = 0; j < APW; ++j) dma16(ap[j] + k0, Ab + (wave * APW + j) * 512);
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) dma16(bp[j] + k0, Bb + (wave * BPW + j) * 8 * BK16);
+    for (int j = 0; j < BPW; ++j) dma16(bp[j] + k0, Bb + (wave * BPW + j) * 512);
   };
 
   f32x16 acc[2][2];
@@ -261,14 +271,14 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_bf16_ring_kernel(
   for (int i = 0; i < 2; ++i) {
     const int ar = wm * 64 + i * 32 + (lane & 31);
     const int br = wn * 64 + i * 32 + (lane & 31);
-    a_row_off[i] = ar * BK16; a_sw[i] = (ar >> 1) & 7;
-    b_row_off[i] = br * BK16; b_sw[i] = (br >> 1) & 7;
+    a_row_off[i] = ar * BK; a_sw[i] = ring_sw<BK>(ar);
+    b_row_off[i] = br * BK; b_sw[i] = ring_sw<BK>(br);
   }
   const int khalf = lane >> 5;
-  const int nk = K / BK16;
+  const int nk = K / BK;
 #pragma unroll
   for (int s = 0; s < NBUF - 1; ++s)
-    if (s < nk) stage(s, s * BK16);
+    if (s < nk) stage(s, s * BK);
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + NBUF - 2 < nk) wait_vmcnt<PW * (NBUF - 2)>(); else wait_vmcnt<0>();
@@ -276,35 +286,50 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_bf16_ring_kernel(
     {
       const int nxt = kt + NBUF - 1;
       int nbuf = buf + NBUF - 1; if (nbuf >= NBUF) nbuf -= NBUF;
-      if (nxt < nk) stage(nbuf, nxt * BK16);
+      if (nxt < nk) stage(nbuf, nxt * BK);
     }
     const bf16raw* Ab = ring + buf * STAGE_ELEMS;
-    const bf16raw* Bb = Ab + RBM * BK16;
-    VTX_MMA_TILE_BF16(Ab, Bb);
+    const bf16raw* Bb = Ab + RBM * BK;
+    bf16x8 fa[2][2], fb[2][2];
+    VTX_LD_FRAGS_BF16(Ab, Bb, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) VTX_LD_FRAGS_BF16(Ab, Bb, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
     if (++buf == NBUF) buf = 0;
   }
   __syncthreads();                              // every wave is done with the ring -> reuse it for staging
-  float* stg = reinterpret_cast<float*>(smem) + wave * 64 * STAGE_LD;
-  stage_acc(stg, acc, lane);
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  epilogue<bf16raw>(ep, stg, m0 + wm * 64, n0 + wn * 64, lane);
+  float* stg = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    stage_acc_half(stg, acc[mi], lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    epilogue<bf16raw, 32>(ep, stg, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
-template <int WM, int NBUF>
+template <int WM, int NBUF, int BK>
 static int launch_ring(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st) {
   constexpr int RBM = WM * 64;
-  const size_t ring_bytes = (size_t)NBUF * (RBM + BN) * BK16 * 2;
-  const size_t stage_bytes = (size_t)WM * 2 * 64 * STAGE_LD * 4;
+  const size_t ring_bytes = (size_t)NBUF * (RBM + BN) * BK * 2;
+  const size_t stage_bytes = (size_t)WM * 2 * 32 * STAGE_LD * 4;
   const size_t lds = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_ring_kernel<WM, NBUF>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_ring_kernel<WM, NBUF, BK>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tiles_m = cdiv(d->M, RBM), tiles_n = cdiv(d->N, BN);
-  hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<WM, NBUF>), dim3(tiles_m * tiles_n), dim3(WM * 128), lds, st, d->M, d->N,
+  hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<WM, NBUF, BK>), dim3(tiles_m * tiles_n), dim3(WM * 128), lds, st, d->M, d->N,
                      d->K, (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
   return check_launch("gemm_nt_ring");
 }
@@ -447,14 +472,16 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   if (d->dtype == VTX_BF16) {
     const size_t lds = STAGE_BYTES > 4 * BM * BK16 * 2 ? STAGE_BYTES : 4 * BM * BK16 * 2;
     const char* nodma = getenv("VTX_GEMM_NODMA");
-    const char* kv = getenv("VTX_GEMM_NT");             // tuning override: dma2 | ring128x3 | ring128x4 | ring256x3
+    const char* kv = getenv("VTX_GEMM_NT");             // tuning override: dma2 | ring128x3 | ring128x4k32 | ring256x3 | ring256x3k32 | ring256x4k32
     const bool dma_ok = d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0);
     // default: the 256x128 ring for big problems; the small square projections (N,K <= 768) do better with two
     // co-resident 128x128 workgroups per CU whose prologue/epilogue overlap (measured, tools/kernel_bench.py)
     std::string variant = kv ? kv : ((d->M >= 1024 && !(d->N <= 768 && d->K <= 768)) ? "ring256x3" : "dma2");
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3") return launch_ring<4, 3>(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring128x3") return launch_ring<2, 3>(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 4 && variant == "ring128x4") return launch_ring<2, 4>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3") return launch_ring<4, 3, 64>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3k32") return launch_ring<4, 3, 32>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x4k32") return launch_ring<4, 4, 32>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring128x3") return launch_ring<2, 3, 64>(d, ep, st);
+    if (dma_ok && d->K / BK16 >= 3 && variant == "ring128x4k32") return launch_ring<2, 4, 32>(d, ep, st);
     if (dma_ok)
       hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
                          d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
