@@ -169,16 +169,19 @@ def test_gemm_nt_epilogues(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304), (12552, 768, 768)])
+@pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304), (12552, 768, 768),
+                                     (1031, 216, 768), (4099, 3072, 768), (1024, 8, 136)])
 def test_gemm_tn(dtype, M, N1, N2, monkeypatch):
     from vtx import ops
     A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
     ref = q(A, dtype).t() @ q(Bm, dtype)
-    for safe, nodma in ([('0', '0'), ('0', '1'), ('1', '1')] if dtype == torch.bfloat16 else [('0', '0')]):
+    for safe, nodma, tnv in ([('0', '0', 'ring'), ('0', '0', 'dma2'), ('0', '1', 'ring'), ('1', '1', 'ring')]
+                             if dtype == torch.bfloat16 else [('0', '0', 'ring')]):
         monkeypatch.setenv('VTX_TN_SAFE', safe)
         monkeypatch.setenv('VTX_GEMM_NODMA', nodma)
+        monkeypatch.setenv('VTX_GEMM_TN', tnv)
         C, cs = ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2, want_colsum=True)
-        check(f'gemm_tn {dtype} safe={safe} nodma={nodma} {M}x{N1}x{N2}', C.cpu(), ref, 2e-3 if dtype == torch.bfloat16 else 1e-3)
+        check(f'gemm_tn {dtype} safe={safe} nodma={nodma} {tnv} {M}x{N1}x{N2}', C.cpu(), ref, 2e-3 if dtype == torch.bfloat16 else 1e-3)
         check(f'gemm_tn colsum {dtype} safe={safe} nodma={nodma} {M}x{N1}x{N2}', cs.cpu(), q(A, dtype).sum(0), 1e-3)
     monkeypatch.setenv('VTX_TN_SAFE', '0')
     monkeypatch.setenv('VTX_GEMM_NODMA', '0')

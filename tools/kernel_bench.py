@@ -50,8 +50,11 @@ def main():
                 continue
             A, Bm = r(M, N1), r(M, N2)
             out = torch.empty(N1, N2, device=DEV)
-            t = timeit(lambda: ops.gemm_tn(A, Bm, M, N1, N2, out=out))
-            print(f'gemm_tn {name} {tag:6s} M={M} N1={N1} N2={N2}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TFLOP/s', flush=True)
+            for variant in (['dma2', 'ring'] if dtype == torch.bfloat16 else ['-']):
+                os.environ['VTX_GEMM_TN'] = variant
+                t = timeit(lambda: ops.gemm_tn(A, Bm, M, N1, N2, out=out, want_colsum=True))
+                print(f'gemm_tn {name} {tag:6s} {variant:5s} M={M} N1={N1} N2={N2}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TFLOP/s', flush=True)
+            os.environ.pop('VTX_GEMM_TN', None)
         es = 2 if dtype == torch.bfloat16 else 4
         # attention cores
         qkv = r(B * N, 3 * D)

@@ -474,9 +474,9 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
     const char* nodma = getenv("VTX_GEMM_NODMA");
     const char* kv = getenv("VTX_GEMM_NT");             // tuning override: dma2 | ring128x3 | ring128x4k32 | ring256x3 | ring256x3k32 | ring256x4k32
     const bool dma_ok = d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0);
-    // default: the 256x128 ring for big problems; the small square projections (N,K <= 768) do better with two
-    // co-resident 128x128 workgroups per CU whose prologue/epilogue overlap (measured, tools/kernel_bench.py)
-    std::string variant = kv ? kv : ((d->M >= 1024 && !(d->N <= 768 && d->K <= 768)) ? "ring256x3" : "dma2");
+    // default (measured, tools/kernel_bench.py): the 256x128 ring with BK=32 -- 72 KB of LDS, two co-resident
+    // workgroups per CU whose prologue / epilogue overlap each other's main loop
+    std::string variant = kv ? kv : (d->M >= 1024 ? "ring256x3k32" : "dma2");
     if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3") return launch_ring<4, 3, 64>(d, ep, st);
     if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3k32") return launch_ring<4, 3, 32>(d, ep, st);
     if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x4k32") return launch_ring<4, 4, 32>(d, ep, st);

@@ -18,6 +18,7 @@
 // second kernel sums in a fixed order: deterministic, no atomics.
 // Algorithmic FLOPs per launch: 2*M*N1*N2.
 #include <stdlib.h>
+#include <string>
 #include "gemm_common.h"
 
 namespace vtx {
@@ -333,6 +334,190 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_dma_kernel(
   tn_store(out, stage, split, r0 + wm * 64, c0 + wn * 64, lane);
 }
 
+// ---- bf16, 256x128 output tile, LDS-DMA ring with counted vmcnt ----------------------------
+// Mirror of gemm_nt's <4,3,32> ring: 8 waves (4x2, each 64x64), 32 token rows per stage
+// (A [32][256] + B [32][128] bf16 = 24 KB), 3 stages = 72 KB -> two workgroups per CU.  Chunk
+// swizzle ^((row&3)<<2) on the DMA source side keeps the transpose reads conflict free.
+template <int N> __device__ inline void tn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+constexpr int TR_BKM = 32, TR_NBUF = 3, TR_A_LD = 256, TR_B_LD = 128;
+constexpr int TR_STAGE = TR_BKM * (TR_A_LD + TR_B_LD);      // elements per stage
+
+__global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
+    int M, int m_per_split, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* ring = reinterpret_cast<bf16raw*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x / tiles12;
+  const int tile = blockIdx.x - split * tiles12;
+  const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+  const int r0 = t1 * 256, c0 = t2 * 128;
+  const int m_begin = split * m_per_split;
+  const int m_end = min(M, m_begin + m_per_split);
+
+  // DMA: A piece = 2 rows x 512 B (lane -> row lane>>5, physical chunk lane&31), 2 pieces per wave;
+  //      B piece = 4 rows x 256 B (lane -> row lane>>4, physical chunk lane&15), 1 piece per wave.
+  const int a_prow = lane >> 5;                       // row within the A piece; piece p covers rows 2p, 2p+1
+  const int b_prow = lane >> 4;
+  int a_col[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 2 + a_prow;
+    const int lc = (lane & 31) ^ ((row & 3) << 2);
+    a_col[j] = (r0 + lc * 8) < out.N1 ? r0 + lc * 8 : 0;
+  }
+  const int b_row = wave * 4 + b_prow;
+  const int b_lc = (lane & 15) ^ ((b_row & 3) << 2);
+  const int b_col = (c0 + b_lc * 8) < out.N2 ? c0 + b_lc * 8 : 0;
+  auto stage = [&](int buf, int mt) {
+    bf16raw* Ab = ring + buf * TR_STAGE;
+    bf16raw* Bb = Ab + TR_BKM * TR_A_LD;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 2 + a_prow;
+      tn_dma16(A + map_row(amap, mt + row) * lda + a_col[j], Ab + (wave * 2 + j) * 512);
+    }
+    tn_dma16(B + map_row(bmap, mt + b_row) * ldb + b_col, Bb + wave * 512);
+  };
+  // ragged tile (registers, zero fill)
+  auto stage_ragged = [&](int buf, int mt) {
+    bf16raw* Ab = ring + buf * TR_STAGE;
+    bf16raw* Bb = Ab + TR_BKM * TR_A_LD;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = (tid >> 5) + 16 * it;
+      const int lc = (tid & 31) ^ ((row & 3) << 2);
+      uint4 va = make_uint4(0, 0, 0, 0);
+      if (mt + row < m_end && r0 + lc * 8 < out.N1)
+        va = *reinterpret_cast<const uint4*>(A + map_row(amap, mt + row) * lda + r0 + lc * 8);
+      *reinterpret_cast<uint4*>(Ab + row * TR_A_LD + (tid & 31) * 8) = va;
+    }
+    {
+      const int row = tid >> 4;
+      const int lc = (tid & 15) ^ ((row & 3) << 2);
+      uint4 vb = make_uint4(0, 0, 0, 0);
+      if (mt + row < m_end && c0 + lc * 8 < out.N2)
+        vb = *reinterpret_cast<const uint4*>(B + map_row(bmap, mt + row) * ldb + c0 + lc * 8);
+      *reinterpret_cast<uint4*>(Bb + row * TR_B_LD + (tid & 15) * 8) = vb;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_sw = ((lane & 15) >> 2) << 2;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = wm * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int cb = wn * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    a_off[i] = tr_row * TR_A_LD + (((ca >> 3) ^ tr_sw) << 3) + (ca & 7);
+    b_off[i] = tr_row * TR_B_LD + (((cb >> 3) ^ tr_sw) << 3) + (cb & 7);
+  }
+  const bool do_cs = out.cslab != nullptr && t2 == 0;
+  const int cs_row = tid >> 5, cs_pc = tid & 31;                  // rows cs_row, cs_row+16 (same row&3)
+  const int cs_chunk = cs_pc ^ ((cs_row & 3) << 2);
+  float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int span = m_end - m_begin;
+  const int n_full = span > 0 ? span / TR_BKM : 0;
+  const int n_tiles = n_full + ((span > 0 && span % TR_BKM) ? 1 : 0);
+  // prologue: tiles 0 .. NBUF-2.  A ragged tile (always the last one) goes through registers.
+#pragma unroll
+  for (int s = 0; s < TR_NBUF - 1; ++s)
+    if (s < n_full) stage(s, m_begin + s * TR_BKM);
+  int buf = 0;
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    if (ti >= n_full) {                                                  // only ti == n_tiles-1; its slot was drained
+      stage_ragged(buf, m_begin + ti * TR_BKM);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                // ds_writes visible before the raw barrier
+    }
+    if (ti + TR_NBUF - 2 < n_full) tn_wait_vmcnt<3 * (TR_NBUF - 2)>(); else tn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    {
+      const int nxt = ti + TR_NBUF - 1;
+      int nbuf = buf + TR_NBUF - 1; if (nbuf >= TR_NBUF) nbuf -= TR_NBUF;
+      if (nxt < n_full) stage(nbuf, m_begin + nxt * TR_BKM);
+    }
+    const bf16raw* Ab = ring + buf * TR_STAGE;
+    const bf16raw* Bb = Ab + TR_BKM * TR_A_LD;
+    if (do_cs) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const uint4 v = *reinterpret_cast<const uint4*>(Ab + (cs_row + 16 * it) * TR_A_LD + cs_pc * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          csum[2 * j] += __uint_as_float(w[j] << 16);
+          csum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < TR_BKM / 16; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16raw* pa = Ab + ks * 16 * TR_A_LD + a_off[i];
+        const bf16raw* pb = Bb + ks * 16 * TR_B_LD + b_off[i];
+        union { bf16x8 v; s16x4 h[2]; } ua, ub;
+        ua.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+        ua.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * TR_A_LD));
+        ub.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+        ub.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * TR_B_LD));
+        af[i] = ua.v; bfr[i] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (++buf == TR_NBUF) buf = 0;
+  }
+  __syncthreads();
+  if (do_cs) {
+    float* red = reinterpret_cast<float*>(smem);            // [16][256]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[cs_row * 256 + cs_chunk * 8 + j] = csum[j];
+    __syncthreads();
+    if (tid < 256 && r0 + tid < out.N1) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += red[r * 256 + tid];
+      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
+    }
+    __syncthreads();
+  }
+  float* stg = reinterpret_cast<float*>(smem) + wave * 32 * STAGE_LD;
+  float* dst = out.slab + (long)split * out.slab_stride;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    stage_acc_half(stg, acc[mi], lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int e = 0; e < 4; ++e) {
+      const int rw = e * 8 + (lane >> 3);
+      const int r = r0 + wm * 64 + mi * 32 + rw, c = c0 + wn * 64 + (lane & 7) * 8;
+      if (r >= out.N1 || c >= out.N2) continue;
+      const float* sp = stg + rw * STAGE_LD + (lane & 7) * 8;
+      float* d = dst + (long)r * out.N2 + c;
+      *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(sp);
+      *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(sp + 4);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(NT_THREADS) void gemm_tn_f32_kernel(
     int M, int m_per_split, const float* __restrict__ A, long lda, vtx_rowmap amap,
     const float* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
@@ -518,7 +703,28 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     const char* safe_env = getenv("VTX_TN_SAFE");   // diagnostic path, read per call
     const bool safe = safe_env && atoi(safe_env) != 0;
     const char* nodma = getenv("VTX_GEMM_NODMA");
-    if (!safe && !(nodma && atoi(nodma) != 0)) {
+    const char* tnv = getenv("VTX_GEMM_TN");            // tuning override: ring | dma2
+    const bool want_ring = !(tnv && std::string(tnv) == "dma2") && d->M >= 1024;
+    if (!safe && !(nodma && atoi(nodma) != 0) && want_ring) {
+      const int tiles1r = cdiv(d->N1, 256);
+      int s_r = cdiv(512, tiles1r * tiles2);
+      if (s_r > splits) s_r = splits;
+      int m_per_r = cdiv(cdiv(d->M, s_r), TR_BKM) * TR_BKM;
+      const size_t ring_bytes = (size_t)TR_NBUF * TR_STAGE * 2;
+      const size_t lds_r = ring_bytes > (size_t)8 * 32 * STAGE_LD * 4 ? ring_bytes : (size_t)8 * 32 * STAGE_LD * 4;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(gemm_tn_bf16_ring_kernel, dim3(tiles1r * tiles2 * s_r), dim3(512), lds_r, st, d->M, m_per_r,
+                         (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1r * tiles2, out);
+      int rc_r = check_launch("gemm_tn_ring");
+      if (rc_r) return rc_r;
+      if (!d->colsum) return launch_reduce_partials(out.slab, s_r, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
+      return launch_reduce_partials(out.slab, s_r, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
+                                    d->colsum, w_elems, d->colsum_accumulate);
+    } else if (!safe && !(nodma && atoi(nodma) != 0)) {
       const size_t need_d = (size_t)4 * TN_BKM * TN_DLD * 2;
       const size_t lds_d = STAGE_BYTES > need_d ? STAGE_BYTES : need_d;
       hipLaunchKernelGGL(gemm_tn_bf16_dma_kernel, grid, block, lds_d, st, d->M, m_per, (const bf16raw*)d->A, d->lda,
