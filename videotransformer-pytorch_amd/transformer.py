@@ -63,8 +63,16 @@ class DropPath(nn.Module):
             return None
         keep = 1 - p
         u = torch.rand((rows,) + (1,) * (ndim - 1))
-        mask = (keep + u).floor_()
-        return (mask / keep).reshape(rows).to(device=device, dtype=torch.float32, non_blocking=True)
+        scale = ((keep + u).floor_() / keep).reshape(rows).to(torch.float32)
+        if device.type != 'cuda':
+            return scale
+        # Upload through PINNED memory with a truly asynchronous copy: a pageable-memory H2D copy is
+        # stream-ordered but blocks the host until the GPU has drained the stream, i.e. every DropPath
+        # call (33 per TimeSformer-B step) would stall the launch pipeline.  The caching host allocator
+        # keeps the pinned block alive until the copy has executed.
+        staged = torch.empty(rows, dtype=torch.float32, pin_memory=True)
+        staged.copy_(scale)
+        return staged.to(device=device, non_blocking=True)
 
     def forward(self, x):
         s = self.scale_vector(x.shape[0], x.ndim, x.device)
