@@ -9,6 +9,9 @@ dev = torch.device('cuda:0')
 vtx.set_precision('bf16')
 model = V.TimeSformer(num_frames=8).to(dev).train()
 head = T.ClassificationHead(400, 768).to(dev).train()
+if os.environ.get('NO_DROPPATH'):
+    for m in model.modules():
+        if isinstance(m, T.DropPath): m.dropout_p = 0.0
 params = list(model.parameters()) + list(head.parameters())
 opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, nesterov=True)
 for B in [int(a) for a in sys.argv[1:]] or [16, 32, 48, 64]:

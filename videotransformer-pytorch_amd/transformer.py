@@ -66,13 +66,8 @@ class DropPath(nn.Module):
         scale = ((keep + u).floor_() / keep).reshape(rows).to(torch.float32)
         if device.type != 'cuda':
             return scale
-        # Upload through PINNED memory with a truly asynchronous copy: a pageable-memory H2D copy is
-        # stream-ordered but blocks the host until the GPU has drained the stream, i.e. every DropPath
-        # call (33 per TimeSformer-B step) would stall the launch pipeline.  The caching host allocator
-        # keeps the pinned block alive until the copy has executed.
-        staged = torch.empty(rows, dtype=torch.float32, pin_memory=True)
-        staged.copy_(scale)
-        return staged.to(device=device, non_blocking=True)
+        # no hipMemcpy: a copy kernel reads the mask from pinned host memory (see vtx.ops.upload_f32)
+        return vtx.ops.upload_f32(scale, device)
 
     def forward(self, x):
         s = self.scale_vector(x.shape[0], x.ndim, x.device)
