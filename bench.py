@@ -46,10 +46,18 @@ def parse():
 
 
 def _host_cores():
+    """CPUs this process may really use: min(affinity, cgroup CPU quota)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline_subprocess(frames, budget_s=150):
@@ -101,6 +109,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    # host threads: never more than the cgroup CPU quota allows (an oversubscribed ATen pool gets the
+    # whole process CFS-throttled, which shows up as ~90 ms launch stalls)
+    torch.set_num_threads(max(1, min(_host_cores() // max(world, 1), 16)))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:

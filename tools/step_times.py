@@ -9,6 +9,23 @@ dev = torch.device('cuda:0')
 vtx.set_precision('bf16')
 model = V.TimeSformer(num_frames=8).to(dev).train()
 head = T.ClassificationHead(400, 768).to(dev).train()
+mode = os.environ.get('DP_MODE')
+if mode:
+    import types
+    def sv(self, rows, ndim, device):
+        p = self.dropout_p
+        if not p or not self.training: return None
+        keep = 1 - p
+        if mode == 'gpu_rng':
+            return ((keep + torch.rand(rows, device=device)).floor_() / keep)
+        if mode == 'cpu_rng_noupload':
+            u = torch.rand((rows,) + (1,) * (ndim - 1))
+            return torch.ones(rows, device=device)
+        if mode == 'upload_only':
+            return vtx.ops.upload_f32(torch.ones(rows), device)
+    for m in model.modules():
+        if isinstance(m, T.DropPath): m.scale_vector = types.MethodType(sv, m)
+print('threads', torch.get_num_threads(), 'affinity', len(os.sched_getaffinity(0)), 'cpu.max', open('/sys/fs/cgroup/cpu.max').read().strip() if os.path.exists('/sys/fs/cgroup/cpu.max') else 'n/a', flush=True)
 if os.environ.get('NO_DROPPATH'):
     for m in model.modules():
         if isinstance(m, T.DropPath): m.dropout_p = 0.0

@@ -62,8 +62,12 @@ class DropPath(nn.Module):
         if not p or not self.training:
             return None
         keep = 1 - p
-        u = torch.rand((rows,) + (1,) * (ndim - 1))
-        scale = ((keep + u).floor_() / keep).reshape(rows).to(torch.float32)
+        u = torch.rand((rows,) + (1,) * (ndim - 1))          # the reference's draw (shape and generator)
+        # mask arithmetic in NumPy, not ATen: on many-core hosts with a cgroup CPU quota the ATen
+        # intra-op pool (128 threads on the bench box, quota 16 CPUs) gets the whole process
+        # CFS-throttled for ~90 ms at a time when tiny CPU ops run between kernel launches
+        scale = np.floor(np.float32(keep) + u.numpy().reshape(rows)) / np.float32(keep)
+        scale = torch.from_numpy(scale.astype(np.float32, copy=False))
         if device.type != 'cuda':
             return scale
         # no hipMemcpy: a copy kernel reads the mask from pinned host memory (see vtx.ops.upload_f32)

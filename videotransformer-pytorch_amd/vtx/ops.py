@@ -281,7 +281,7 @@ def upload_f32(values_cpu, device):
         cap = max(1024, 1 << (n - 1).bit_length())
         slot = [torch.empty(cap, dtype=torch.float32, pin_memory=True), None]
         _pinned_slots.append(slot)
-    slot[0][:n].copy_(values_cpu.reshape(-1))
+    slot[0].numpy()[:n] = values_cpu.reshape(-1).numpy()        # NumPy copy: keep ATen's CPU thread pool out of the step
     out = torch.empty(n, dtype=torch.float32, device=device)
     call('vtx_cast_from_f32', _lib.VTX_F32, n, slot[0].data_ptr(), out.data_ptr(), stream())
     ev = torch.cuda.Event()
