@@ -222,8 +222,8 @@ static int ln_blocks(int rows) {
 }
 // backward keeps per-block partial sums of dgamma/dbeta: fewer, fatter blocks
 static int ln_bwd_blocks(int rows) {
-  int b = cdiv(rows, LN_WAVES * 8);
-  return b > 512 ? 512 : (b < 1 ? 1 : b);
+  int b = cdiv(rows, LN_WAVES * 4);
+  return b > 2048 ? 2048 : (b < 1 ? 1 : b);
 }
 
 template <typename T>
