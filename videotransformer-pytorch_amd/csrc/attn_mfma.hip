@@ -33,6 +33,7 @@ __device__ inline long m_out_row(const AttnP& p, int s, int i) { return out_row(
 
 constexpr int MA_THREADS = 256;
 constexpr int MA_MAXT = 8;            // up to 8 tiles of 32 rows (Lp <= 256)
+constexpr int MA_KB = 4;              // key tiles per online-softmax block in the forward kernel
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -115,7 +116,7 @@ __device__ inline void store_rows_T(bf16raw* dst_row, const f32x16 (&acc)[2], fl
 }
 
 // ------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(MA_THREADS) void attn_fwd_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+__global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                    bf16raw* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
@@ -133,54 +134,67 @@ __global__ __launch_bounds__(MA_THREADS) void attn_fwd_mfma_kernel(AttnP p, cons
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, q, p.L, ks, lane, rowfn);
-    f32x16 st[MA_MAXT];
-#pragma unroll
-    for (int kt = 0; kt < MA_MAXT; ++kt) {
-      zero16(st[kt]);
-      if (kt < nt) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32, ks, lane), qf[ks], st[kt], 0, 0, 0);
-      }
-    }
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < MA_MAXT; ++kt)
-      if (kt < nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * 32 + crow(r, lane);
-          const float v = key < p.L ? st[kt][r] * c2 : -INFINITY;
-          st[kt][r] = v;
-          m = fmaxf(m, v);
-        }
-      }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MA_MAXT; ++kt)
-      if (kt < nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(st[kt][r] - m); st[kt][r] = e; l += e; }
-      }
-    l += __shfl_xor(l, 32, 64);
+    // Keys in blocks of MA_KB tiles (128 keys) with an online-softmax rescale between blocks: bounds the
+    // live score registers to 64 per lane (two workgroups per CU instead of one).
     f32x16 acc[2];
     zero16(acc[0]);
     zero16(acc[1]);
+    float m = -INFINITY, l = 0.f;
+    for (int kb = 0; kb < nt; kb += MA_KB) {
+      f32x16 st[MA_KB];
 #pragma unroll
-    for (int kt = 0; kt < MA_MAXT; ++kt)
-      if (kt < nt) {
+      for (int t = 0; t < MA_KB; ++t) {
+        zero16(st[t]);
+        if (kb + t < nt) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          float pf[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = st[kt][8 * s2 + j];
-          const bf16x8 pb = pack8(pf);
-#pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2)
-            acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, kt * 32 + 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks)
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, (kb + t) * 32, ks, lane), qf[ks], st[t], 0, 0, 0);
         }
       }
+      float bm = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t)
+        if (kb + t < nt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = (kb + t) * 32 + crow(r, lane);
+            const float v = key < p.L ? st[t][r] * c2 : -INFINITY;
+            st[t][r] = v;
+            bm = fmaxf(bm, v);
+          }
+        }
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m, bm);                 // finite: every block holds at least one real key
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      float bl = 0.f;
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t)
+        if (kb + t < nt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(st[t][r] - m); st[t][r] = e; bl += e; }
+        }
+      bl += __shfl_xor(bl, 32, 64);
+      l = l * alpha + bl;
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n2][r] *= alpha;
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t)
+        if (kb + t < nt) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            float pf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = st[t][8 * s2 + j];
+            const bf16x8 pb = pack8(pf);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+              acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, (kb + t) * 32 + 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
+          }
+        }
+    }
     if (q < p.L) {
       store_rows_T(out + m_out_row(p, s, q) * p.ld_out + h * 64, acc, 1.0f / l, lane);
       if (lane < 32) lse[((long)s * p.H + h) * p.L + q] = m * LN2 + __logf(l);
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(MA_THREADS) void attn_fwd_mfma_kernel(AttnP p, cons
 }
 
 // --------------------------------------------------------------------------- backward: dq
-__global__ __launch_bounds__(MA_THREADS) void attn_bwd_dq_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+__global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                       const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
                                                                       const float* __restrict__ lse, float* __restrict__ delta,
                                                                       bf16raw* __restrict__ dqkv, bf16raw* __restrict__ dqkv_cls) {
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_dq_mfma_kernel(AttnP p, c
 }
 
 // -------------------------------------------------------------------------- backward: dk, dv
-__global__ __launch_bounds__(MA_THREADS) void attn_bwd_dkv_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+__global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                        const bf16raw* __restrict__ dout, const float* __restrict__ lse,
                                                                        const float* __restrict__ delta, bf16raw* __restrict__ dqkv,
                                                                        bf16raw* __restrict__ dqkv_cls) {
