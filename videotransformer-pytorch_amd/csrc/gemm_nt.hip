@@ -217,6 +217,14 @@ __global__ __launch_bounds__(WM * 128, (BK == 32 ? 1024 : 512) / (WM * 128) * (W
     const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
   constexpr int NW = WM * 2;                 // waves
   constexpr int RBM = WM * 64;               // tile rows
+  constexpr int RPP = 512 / BK;              // tile rows per 1-KiB DMA piece
+  constexpr int LPR = BK / 8;                // lanes (16-B chunks) per row
+  constexpr int APW = RBM / RPP / NW;        // A pieces per wave per stage
+  constexpr int BPW = BN / RPP / NW;         // B pieces per wave per stage
+  constexpr int PW = APW + BPW;              // DMA instructions per wave per stage
+  constexpr int KS = BK / 16;                // MFMA k-steps per stage
+  constexpr int STAGE_ELEMS = (RBM + BN) * BK;
+  static_assert(APW >= 1 && BPW >= 1, "tile too small for this many waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* ring = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
