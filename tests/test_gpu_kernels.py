@@ -82,12 +82,12 @@ def test_layernorm_fwd_bwd(dtype, D):
 
 
 # --------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize('variant', ['ring256x3', 'ring256x3k32', 'ring256x4k32', 'ring128x3', 'ring128x4k32', 'dma2'])
+@pytest.mark.parametrize('variant', ['pp256', 'ring256x3', 'ring256x3k32', 'ring256x4k32', 'ring128x3', 'ring128x4k32', 'dma2'])
 def test_gemm_nt_bf16_variants(variant, monkeypatch):
     """Every staging variant of the bf16 NT GEMM (2-buffer DMA, DMA rings with counted vmcnt)."""
     from vtx import ops
     monkeypatch.setenv('VTX_GEMM_NT', variant)
-    for (M, N, K) in [(1568, 2304, 768), (3000, 216, 3072), (1030, 768, 192), (12544, 768, 768)]:
+    for (M, N, K) in [(1568, 2304, 768), (3000, 216, 3072), (1030, 768, 192), (12544, 768, 768), (777, 1000, 128)]:
         A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
         ref = q(A, torch.bfloat16) @ q(W, torch.bfloat16).t() + b.double()
         C = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)

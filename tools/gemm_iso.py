@@ -1,0 +1,20 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'videotransformer-pytorch_amd'), os.path.join(ROOT, 'tools')):
+    sys.path.insert(0, p)
+import torch
+from vtx import ops
+from kernel_bench import timeit
+os.environ['VTX_GEMM_NT'] = 'pp256'
+os.environ['VTX_GEMM_PP_SKEW'] = '0'
+N, K = 3072, 768
+for grid, M in ((8, 2048), (64, 2048 * 8), (256, 2048 * 32)):
+    os.environ['VTX_GEMM_PP_GRID'] = str(grid)
+    for dbg in (0, 1, 4):
+        os.environ['VTX_GEMM_DBG'] = str(dbg)
+        a = torch.randn(M, K, device='cuda').bfloat16()
+        w = torch.randn(N, K, device='cuda').bfloat16()
+        c = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        t = timeit(lambda: ops.gemm_nt(a, w, c, M, N, K))
+        ntile = (M // 256) * (N // 256) / grid
+        print(f'grid={grid} M={M} dbg={dbg}: {t*1e6:8.1f} us  per tile {t*1e6/ntile:6.2f} us ({ntile:.0f} tiles/WG)', flush=True)

@@ -120,21 +120,62 @@ __device__ inline void zero16(f32x16& a) {
 // row index (within a 32-row tile) that accumulator register r of this lane holds
 __device__ inline int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// Store a [32 x 64] result held transposed (lane&31 = row, registers = 64 columns in two C tiles)
-__device__ inline void store_rows_T(bf16raw* dst_row, const f32x16 (&acc)[2], float mul, int lane) {
+constexpr int MA_STAGE_ELEMS = 32 * 64;   // per-wave [32][64] bf16 staging tile for row stores (4 KB)
+
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Store a [32 x 64] result held transposed (lane&31 = row, registers = 64 columns in two C tiles).
+// The accumulator layout gives each lane 8-byte pieces of 32 different rows -- stored directly that
+// is 16 B per row per instruction (measured: 47 us of a 153 us forward).  Stage through a wave-private
+// swizzled LDS tile instead and write whole 128-B rows: 8 lanes x 16 B, 8 rows per instruction.
+// ptr_of_row(r) -> destination of tile row r (64 bf16), or nullptr for a padded row.
+template <typename PtrFn>
+__device__ inline void store_rows_T(bf16raw* stg, const f32x16 (&acc)[2], float mul, int lane, PtrFn ptr_of_row) {
+  const int row = lane & 31;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = nt * 32 + 8 * g + 4 * (lane >> 5);
-      uint2 w;
-      w.x = (uint32_t)f2bf(acc[nt][4 * g] * mul) | ((uint32_t)f2bf(acc[nt][4 * g + 1] * mul) << 16);
-      w.y = (uint32_t)f2bf(acc[nt][4 * g + 2] * mul) | ((uint32_t)f2bf(acc[nt][4 * g + 3] * mul) << 16);
-      *reinterpret_cast<uint2*>(dst_row + col) = w;
+      union { bf16x4 v; uint2 u; } w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w.v[j] = (__bf16)(acc[nt][4 * g + j] * mul);
+      *reinterpret_cast<uint2*>(stg + sw_off(row, col)) = w.u;
+    }
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = i * 8 + (lane >> 3), c = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(stg + r * 64 + ((c ^ sw_of(r)) << 3));
+    bf16raw* dst = ptr_of_row(r);
+    if (dst) *reinterpret_cast<uint4*>(dst + c * 8) = v;
+  }
+  wave_lds_sync();
+}
+
+// Direct variant (8-byte pieces, no staging) for the packed short-sequence kernels below.
+__device__ inline void store_rows_direct(bf16raw* dst_row, const f32x16 (&acc)[2], float mul, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      union { bf16x4 v; uint2 u; } w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w.v[j] = (__bf16)(acc[nt][4 * g + j] * mul);
+      *reinterpret_cast<uint2*>(dst_row + nt * 32 + 8 * g + 4 * (lane >> 5)) = w.u;
     }
 }
 
 // ------------------------------------------------------------------------------ forward
+// One workgroup per (sequence, head): K and V tiles live in LDS, each wave owns query tiles
+// qt = wave, wave+4, ...  Scores stay in registers (S^T = K Q^T so that every lane owns ONE query
+// row: row statistics need a single cross-lane exchange).  The kernel is bound by HBM (128 flop/B)
+// and then by the VALU softmax (v_exp_f32 is quarter rate), so per score element the loop spends
+// one max, one fma, one exp2 and one add: the scale is folded into the fma and the padding mask is
+// applied only to the key tile that actually holds padded keys.
 __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                    bf16raw* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
@@ -143,21 +184,23 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
   const int nt = (p.L + 31) >> 5, Lp = nt * 32;
   bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Vs = Ks + Lp * 64;
+  bf16raw* stg = Vs + Lp * 64 + wave * MA_STAGE_ELEMS;
   auto rowfn = [&](int i) { return m_in_row(p, s, i); };
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, wave * 32 + (lane & 31), p.L, ks, lane, rowfn);
   fill_tiles2(Ks, Vs, Lp, p.L, qkv, p.ld_qkv, D + h * 64, rowfn, qkv, p.ld_qkv, 2 * D + h * 64, rowfn);
   __syncthreads();
   const float c2 = p.scale * LOG2E;
+  const int ragged = (p.L & 31) ? nt - 1 : -1;     // the key tile that holds padded keys
   for (int qt = wave; qt < nt; qt += 4) {
-    const int q = qt * 32 + (lane & 31);
-    bf16x8 qf[4];
+    bf16x8 qn[4];                                  // next query tile's fragments, in flight during this one
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, q, p.L, ks, lane, rowfn);
-    // Keys in blocks of MA_KB tiles (128 keys) with an online-softmax rescale between blocks: bounds the
-    // live score registers to 64 per lane (two workgroups per CU instead of one).
+    for (int ks = 0; ks < 4; ++ks) qn[ks] = frag_global(qkv, p.ld_qkv, h * 64, (qt + 4) * 32 + (lane & 31), p.L, ks, lane, rowfn);
     f32x16 acc[2];
     zero16(acc[0]);
     zero16(acc[1]);
-    float m = -INFINITY, l = 0.f;
+    float m = -1e30f, l = 0.f;                     // running max of the RAW scores (scale > 0)
     for (int kb = 0; kb < nt; kb += MA_KB) {
       f32x16 st[MA_KB];
 #pragma unroll
@@ -169,35 +212,38 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
             st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, (kb + t) * 32, ks, lane), qf[ks], st[t], 0, 0, 0);
         }
       }
-      float bm = -INFINITY;
+      float bm = -1e30f;
 #pragma unroll
       for (int t = 0; t < MA_KB; ++t)
         if (kb + t < nt) {
+          if (kb + t == ragged) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = (kb + t) * 32 + crow(r, lane);
-            const float v = key < p.L ? st[t][r] * c2 : -INFINITY;
-            st[t][r] = v;
-            bm = fmaxf(bm, v);
+            for (int r = 0; r < 16; ++r)
+              if ((kb + t) * 32 + crow(r, lane) >= p.L) st[t][r] = -1e30f;
           }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bm = fmaxf(bm, st[t][r]);
         }
       bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m, bm);                 // finite: every block holds at least one real key
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      const float mn = fmaxf(m, bm);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
       m = mn;
+      const float mc = mn * c2;
       float bl = 0.f;
 #pragma unroll
       for (int t = 0; t < MA_KB; ++t)
         if (kb + t < nt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(st[t][r] - m); st[t][r] = e; bl += e; }
+          for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -mc)); st[t][r] = e; bl += e; }
         }
       bl += __shfl_xor(bl, 32, 64);
       l = l * alpha + bl;
+      if (kb > 0) {
 #pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2)
+        for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n2][r] *= alpha;
+          for (int r = 0; r < 16; ++r) acc[n2][r] *= alpha;
+      }
 #pragma unroll
       for (int t = 0; t < MA_KB; ++t)
         if (kb + t < nt) {
@@ -213,10 +259,14 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
           }
         }
     }
-    if (q < p.L) {
-      store_rows_T(out + m_out_row(p, s, q) * p.ld_out + h * 64, acc, 1.0f / l, lane);
-      if (lane < 32) lse[((long)s * p.H + h) * p.L + q] = m * LN2 + __logf(l);
-    }
+    const int q = qt * 32 + (lane & 31);
+    store_rows_T(stg, acc, 1.0f / l, lane, [&](int r) -> bf16raw* {
+      const int qq = qt * 32 + r;
+      return qq < p.L ? out + m_out_row(p, s, qq) * p.ld_out + h * 64 : nullptr;
+    });
+    if (q < p.L && lane < 32) lse[((long)s * p.H + h) * p.L + q] = (m * c2) * LN2 + __logf(l);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
   }
 }
 
@@ -231,11 +281,13 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
   const int nt = (p.L + 31) >> 5, Lp = nt * 32;
   bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Vs = Ks + Lp * 64;
+  bf16raw* stg = Vs + Lp * 64 + wave * MA_STAGE_ELEMS;
   auto rin = [&](int i) { return m_in_row(p, s, i); };
   auto rout = [&](int i) { return m_out_row(p, s, i); };
   fill_tiles2(Ks, Vs, Lp, p.L, qkv, p.ld_qkv, D + h * 64, rin, qkv, p.ld_qkv, 2 * D + h * 64, rin);
   __syncthreads();
   const float c2 = p.scale * LOG2E;
+  const int ragged = (p.L & 31) ? nt - 1 : -1;
   for (int qt = wave; qt < nt; qt += 4) {
     const int q = qt * 32 + (lane & 31);
     bf16x8 qf[4], df[4];
@@ -265,12 +317,16 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32, ks, lane), qf[ks], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kt * 32, ks, lane), df[ks], dp, 0, 0, 0);
       }
+      // dS = P (dP - delta); the softmax scale is applied once to dq at the store.  Padded keys have
+      // zero K rows, so only their probability needs masking (they would otherwise poison nothing but
+      // cost accuracy in the bf16 pack), and only in the ragged tile.
       float ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + crow(r, lane);
-        const float pr = key < p.L ? __builtin_amdgcn_exp2f(st[r] * c2 - l2) : 0.f;
-        ds[r] = pr * (dp[r] - dl) * p.scale;
+      for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -l2)) * (dp[r] - dl);
+      if (kt == ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + crow(r, lane) >= p.L) ds[r] = 0.f;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -280,11 +336,12 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
           acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Ks, kt * 32 + 16 * s2, n2 * 32, lane), db, acc[n2], 0, 0, 0);
       }
     }
-    if (q < p.L) {
-      bf16raw* dst = (p.mode == VTX_ATTN_SPACE && q == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
-                                                          : dqkv + m_in_row(p, s, q) * p.ld_dqkv + h * 64;
-      store_rows_T(dst, acc, 1.0f, lane);
-    }
+    store_rows_T(stg, acc, p.scale, lane, [&](int r) -> bf16raw* {
+      const int qq = qt * 32 + r;
+      if (qq >= p.L) return nullptr;
+      return (p.mode == VTX_ATTN_SPACE && qq == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
+                                                    : dqkv + m_in_row(p, s, qq) * p.ld_dqkv + h * 64;
+    });
   }
 }
 
@@ -299,10 +356,18 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   const int nt = (p.L + 31) >> 5, Lp = nt * 32;
   bf16raw* Qs = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Os = Qs + Lp * 64;
-  float* Ls = reinterpret_cast<float*>(Os + Lp * 64);   // lse * log2(e), +huge on padded rows
+  bf16raw* stg = Os + Lp * 64 + wave * MA_STAGE_ELEMS;
+  float* Ls = reinterpret_cast<float*>(Os + Lp * 64 + 4 * MA_STAGE_ELEMS);   // lse * log2(e), +huge on padded rows
   float* Ds = Ls + Lp;
   auto rin = [&](int i) { return m_in_row(p, s, i); };
   auto rout = [&](int i) { return m_out_row(p, s, i); };
+  const int key = wave * 32 + (lane & 31);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = frag_global(qkv, p.ld_qkv, D + h * 64, key, p.L, ks, lane, rin);
+    vf[ks] = frag_global(qkv, p.ld_qkv, 2 * D + h * 64, key, p.L, ks, lane, rin);
+  }
   fill_tiles2(Qs, Os, Lp, p.L, qkv, p.ld_qkv, h * 64, rin, dout, p.ld_dout, h * 64, rout);
   for (int i = threadIdx.x; i < Lp; i += MA_THREADS) {
     const long li = ((long)s * p.H + h) * p.L + i;
@@ -312,12 +377,11 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   __syncthreads();
   const float c2 = p.scale * LOG2E;
   for (int kt = wave; kt < nt; kt += 4) {
-    const int key = kt * 32 + (lane & 31);
-    bf16x8 kf[4], vf[4];
+    bf16x8 kn[4], vn[4];                           // next key tile's fragments, in flight during this one
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = frag_global(qkv, p.ld_qkv, D + h * 64, key, p.L, ks, lane, rin);
-      vf[ks] = frag_global(qkv, p.ld_qkv, 2 * D + h * 64, key, p.L, ks, lane, rin);
+      kn[ks] = frag_global(qkv, p.ld_qkv, D + h * 64, key + (kt - wave + 4) * 32, p.L, ks, lane, rin);
+      vn[ks] = frag_global(qkv, p.ld_qkv, 2 * D + h * 64, key + (kt - wave + 4) * 32, p.L, ks, lane, rin);
     }
     f32x16 dk[2], dv[2];
     zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
@@ -330,6 +394,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qt * 32, ks, lane), kf[ks], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Os, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
+      // padded query rows: Ls = +huge -> P = 0; padded keys only feed dk/dv rows that are never stored
       float pr[16], ds[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -340,9 +405,9 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
-          const float e = __builtin_amdgcn_exp2f(st[r] * c2 - lv[j]);
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lv[j]));
           pr[r] = e;
-          ds[r] = e * (dp[r] - dvv[j]) * p.scale;
+          ds[r] = e * (dp[r] - dvv[j]);            // the softmax scale is applied once to dk at the store
         }
       }
 #pragma unroll
@@ -356,12 +421,15 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
         }
       }
     }
-    if (key < p.L) {
-      bf16raw* base = (p.mode == VTX_ATTN_SPACE && key == 0) ? dqkv_cls + (long)s * p.ld_dqkv
-                                                             : dqkv + m_in_row(p, s, key) * p.ld_dqkv;
-      store_rows_T(base + D + h * 64, dk, 1.0f, lane);
-      store_rows_T(base + 2 * D + h * 64, dv, 1.0f, lane);
-    }
+    auto base_of = [&](int r) -> bf16raw* {
+      const int kk = kt * 32 + r;
+      if (kk >= p.L) return nullptr;
+      return (p.mode == VTX_ATTN_SPACE && kk == 0) ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + m_in_row(p, s, kk) * p.ld_dqkv;
+    };
+    store_rows_T(stg, dk, p.scale, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + D + h * 64 : nullptr; });
+    store_rows_T(stg, dv, 1.0f, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + 2 * D + h * 64 : nullptr; });
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
   }
 }
 
@@ -376,10 +444,6 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
 constexpr int SM_WAVE_LDS_FWD = 32 * 64 * 2;                   // V tile
 constexpr int SM_WAVE_LDS_BWD = 3 * 32 * 64 * 2 + 2 * 32 * 4;   // K, Q, dO tiles + lse + delta
 
-__device__ inline void wave_lds_sync() {
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-}
 __device__ inline void put_tile(bf16raw* lds, const bf16x8 (&f)[4], int lane) {
   const int row = lane & 31;
 #pragma unroll
@@ -449,7 +513,7 @@ __global__ __launch_bounds__(MA_THREADS) void attn_fwd_small_kernel(AttnP p, int
       acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
   }
   if (valid) {
-    store_rows_T(out + (row0 + i) * p.ld_out + h * 64, acc, 1.0f / l, lane);
+    store_rows_direct(out + (row0 + i) * p.ld_out + h * 64, acc, 1.0f / l, lane);
     if (lane < 32) {
       const long sq = (row0 + i) / L;
       lse[(sq * p.H + h) * L + (row0 + i - sq * L)] = m * LN2 + __logf(l);
@@ -527,7 +591,7 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int
       for (int n2 = 0; n2 < 2; ++n2)
         acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Ks, 16 * s2, n2 * 32, lane), db, acc[n2], 0, 0, 0);
     }
-    if (valid) store_rows_T(dqkv + (row0 + i) * p.ld_dqkv + h * 64, acc, 1.0f, lane);
+    if (valid) store_rows_direct(dqkv + (row0 + i) * p.ld_dqkv + h * 64, acc, 1.0f, lane);
   }
   // ---- phase 2: lanes = keys.  dV^T = dO^T P, dK^T = Q^T dS
   {
@@ -570,8 +634,8 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int
     }
     if (valid) {
       bf16raw* base = dqkv + (row0 + i) * p.ld_dqkv;
-      store_rows_T(base + D + h * 64, dk, 1.0f, lane);
-      store_rows_T(base + 2 * D + h * 64, dv, 1.0f, lane);
+      store_rows_direct(base + D + h * 64, dk, 1.0f, lane);
+      store_rows_direct(base + 2 * D + h * 64, dv, 1.0f, lane);
     }
   }
 }
@@ -599,9 +663,16 @@ int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const 
   return check_launch("attn_bwd_small");
 }
 
+template <typename K>
+static void allow_lds(K kernel, size_t lds) {
+  // > 64 KB of dynamic LDS needs an explicit opt-in (Lp = 256: 64 KB of tiles + 16 KB of staging)
+  if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
   const int Lp = ((p.L + 31) >> 5) * 32;
-  const size_t lds = (size_t)2 * Lp * 64 * 2;
+  const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
+  allow_lds(attn_fwd_mfma_kernel, lds);
   hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv, (bf16raw*)out, lse);
   return check_launch("attn_fwd_mfma");
 }
@@ -609,7 +680,9 @@ int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse,
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
   const int Lp = ((p.L + 31) >> 5) * 32;
-  const size_t lds = (size_t)2 * Lp * 64 * 2;
+  const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
+  allow_lds(attn_bwd_dq_mfma_kernel, lds);
+  allow_lds(attn_bwd_dkv_mfma_kernel, lds + (size_t)2 * Lp * 4);
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv,
                      (const bf16raw*)o, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
   int rc = check_launch("attn_bwd_dq_mfma");

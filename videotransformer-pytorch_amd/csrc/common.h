@@ -19,11 +19,17 @@ __host__ __device__ inline float bf2f(bf16raw v) {
   union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
 }
 __host__ __device__ inline bf16raw f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // gfx950 converts in hardware (v_cvt_pk_bf16_f32, RNE, quiet NaN); the bit-twiddling below compiles
+  // to a ~12-instruction exec-masked sequence per element, which dominated the GEMM epilogues.
+  union { __bf16 b; bf16raw r; } c; c.b = (__bf16)f; return c.r;
+#else
   union { uint32_t u; float f; } c; c.f = f;
   uint32_t u = c.u;
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16raw)((u >> 16) | 0x40);  // quiet NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16raw)(u >> 16);
+#endif
 }
 
 // Element-type traits: T is `float` (VTX_F32) or `bf16raw` (VTX_BF16).
@@ -59,10 +65,10 @@ __device__ inline void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 __device__ inline void store8(bf16raw* p, const float (&v)[8]) {
-  uint32_t w[4];
+  bf16x8 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
-  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+  *reinterpret_cast<bf16x8*>(p) = o;
 }
 
 // ---- row maps ---------------------------------------------------------------

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(WM * 128, (BK == 32 ? 1024 : 512) / (WM * 128) * (W
     stage_acc_half(stg, acc[mi], lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    epilogue<bf16raw, 32>(ep, stg, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+    epilogue<bf16raw, 32, (BK == 32 ? 1 : 4)>(ep, stg, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
@@ -332,6 +332,221 @@ static int launch_ring(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<WM, NBUF, BK>), dim3(tiles_m * tiles_n), dim3(WM * 128), lds, st, d->M, d->N,
                      d->K, (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);
   return check_launch("gemm_nt_ring");
+}
+
+// ------------------------------------------------------------------ bf16, 256x256 tile, two staggered wave groups
+// 8 waves as 2(M) x 4(N), each owning a 128x64 block of the tile (8 accumulators of 32x32).  Waves
+// w and w+4 share a SIMD and sit in different groups (wr = w>>2); group 1 runs ONE barrier behind
+// group 0, so between any two barriers one wave of every SIMD is in an MFMA section (8 MFMAs =
+// 256 matrix-pipe cycles) while its partner is in a load section (LDS fragment reads + 2 LDS-DMA
+// pieces) -- the matrix pipe of every SIMD always has exactly one client.
+//
+// A K tile (64 deep) takes four phases per wave; the wave's block is cut into quadrants
+//   P1: read A0 (rows 0..63 of the block), B0 (cols 0..31)   MFMA A0 x B0
+//   P2: read B1 (cols 32..63)                                 MFMA A0 x B1
+//   P3: read A1 (rows 64..127, reusing A0's registers)        MFMA A1 x B1
+//   P4: --                                                    MFMA A1 x B0
+// The LDS image of a K tile is grouped the same way -- region A0 holds the "A0 rows" of BOTH wave
+// rows, B0 the "B0 columns" of all four wave columns, ... (16 KB each, [128][64] bf16, 16-B chunks
+// XOR-swizzled with (row>>1)&7 on the DMA source side) -- so a region is read in exactly one phase
+// and can be refilled right after it: two K-tile buffers (128 KB) carry 7 regions of lookahead.
+// Phase q of tile t issues region (A1,t+1) / (A0,t+2) / (B0,t+2) / (B1,t+2) for q = 1..4.
+//   WAR: the overwritten copy was last read >= 1 full phase earlier and every load section retires
+//        its reads (lgkmcnt(0)) BEFORE its barrier, so both groups are past them.
+//   RAW: P4 waits vmcnt(6) (everything but the 3 youngest regions = all of tile t+1 has landed),
+//        then the barrier publishes it; tile t+1 is first read one phase later.
+// Past the last tile the DMA source is clamped to the last tile (the regions written are never read).
+constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_THREADS = 512;
+constexpr int PP_REGION = 128 * PP_BK;          // elements per region
+constexpr int PP_BUF = 4 * PP_REGION;           // elements per K-tile buffer: [A0 | B0 | B1 | A1]
+constexpr int PP_RING_BYTES = 2 * PP_BUF * 2;   // 131072
+constexpr int PP_STG_LD = 64;                   // staging rows are unpadded: 8 waves x [16][64] fp32 = 32 KB
+constexpr int PP_LDS_BYTES = PP_RING_BYTES + 8 * 16 * PP_STG_LD * 4;   // 163840 = all of the CU's LDS
+constexpr int PP_GRID = 256;                    // persistent: one workgroup per CU
+
+__device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Persistent: workgroup b (XCD b%8, slot b/8) walks the tiles of its XCD's contiguous tile range in
+// steps of gridDim/8.  The C tile is 128 KB, and a non-persistent launch exposes its write-out
+// (measured at K = 768: 345 us with stores, 247 us without, 206 us without the epilogue at all):
+// here the next tile's first 7 regions are requested BEFORE the epilogue of the finished tile, the
+// epilogue stages through its own 32 KB of LDS, and its stores drain under the next main loop.
+// (vmcnt counts loads and stores together; a counted wait can therefore over-wait on stores but never
+// under-wait on the DMA, because loads retire in order among themselves.)
+__global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
+    int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, EpiParams ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  float* stg = reinterpret_cast<float*>(smem + PP_RING_BYTES) + wave * 16 * PP_STG_LD;
+  const int nk = K / PP_BK;
+
+  // this workgroup's tiles: t = first + i * step, i = 0 .. count-1
+  const int per = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = tiles_total >> 3, rem = tiles_total & 7;
+  const int xstart = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int xcount = xcd < rem ? q + 1 : q;
+  if (slot >= xcount) return;
+  // De-synchronise the CUs.  Every tile takes the same time, so all 256 workgroups would reach their
+  // epilogues together and share HBM's write bandwidth for the 128-KB C tiles (measured: the stores
+  // then cost their full HBM time, ~10 us per tile, un-overlapped).  Workgroups that own one tile
+  // fewer than the busiest ones have a tile's worth of slack: spend it up front, spread uniformly.
+  {
+    const int nfull = xcount % per;              // slots [0, nfull) own ceil(xcount/per) tiles
+    if (nfull != 0 && slot >= nfull && tile_ticks > 0) {
+      const long wait = (long)tile_ticks * (2 * (slot - nfull) + 1) / (2 * (per - nfull));
+      const long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+
+  const bf16raw* src[4][2];                      // region kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    m0 = tm * PP_BM; n0 = tn * PP_BN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                // this wave owns pieces 2*wave, 2*wave+1 (8 region rows each)
+      const int rho = (wave * 2 + j) * 8 + (lane >> 3);
+      const int c = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
+      int ma0 = m0 + (rho >> 6) * 128 + (rho & 63), ma1 = ma0 + 64;
+      if (ma0 >= M) ma0 = M - 1;
+      if (ma1 >= M) ma1 = M - 1;
+      int nb0 = n0 + (rho >> 5) * 64 + (rho & 31), nb1 = nb0 + 32;
+      if (nb0 >= N) nb0 = N - 1;
+      if (nb1 >= N) nb1 = N - 1;
+      src[0][j] = A + map_row(amap, ma0) * lda + c;
+      src[3][j] = A + map_row(amap, ma1) * lda + c;
+      src[1][j] = B + (long)nb0 * ldb + c;
+      src[2][j] = B + (long)nb1 * ldb + c;
+    }
+  };
+  auto issue = [&](int kind, int kt) {           // region `kind` of K tile kt -> buffer kt&1
+    bf16raw* dst = lds + (kt & 1) * PP_BUF + kind * PP_REGION + wave * 1024;
+    dma16(src[kind][0] + kt * PP_BK, dst);
+    dma16(src[kind][1] + kt * PP_BK, dst + 512);
+  };
+  auto prologue = [&]() {                        // tile 0 complete + 3 regions of tile 1 (nk >= 2)
+    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+    issue(0, 1); issue(1, 1); issue(2, 1);
+  };
+
+  // fragment addresses (elements): row (lane&31) of a 32-row group, chunk (2*ks + lane>>5) ^ swizzle;
+  // the swizzle (row>>1)&7 only depends on lane&31 because every group starts at a multiple of 32.
+  const int l31 = lane & 31;
+  int fr[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fr[ks] = l31 * PP_BK + (((2 * ks + (lane >> 5)) ^ ((l31 >> 1) & 7)) << 3);
+  const int a_grp = wr * 64 * PP_BK;             // first row of this wave's rows inside region A0 / A1
+  const int b_grp = wc * 32 * PP_BK;             // ... inside region B0 / B1
+
+#define PP_READ_A(buf_, kind_)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)       \
+      fa[i][ks] = *reinterpret_cast<const bf16x8*>(lds + (buf_) * PP_BUF + (kind_) * PP_REGION + a_grp + i * 32 * PP_BK + fr[ks]);
+#define PP_READ_B(buf_, kind_, fb_)                                                                    \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      fb_[ks] = *reinterpret_cast<const bf16x8*>(lds + (buf_) * PP_BUF + (kind_) * PP_REGION + b_grp + fr[ks]);
+#define PP_MMA(i0_, j_, fb_)                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                       \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int i = 0; i < 2; ++i)       \
+      acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+#define PP_BAR() __builtin_amdgcn_s_barrier()
+
+  const int step = per;
+  int t = xstart + slot;
+  const int tend = xstart + xcount;
+  set_tile(t);
+  prologue();
+  while (true) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[2][4], fb0[4], fb1[4];
+    wait_vmcnt<6>();                              // tile 0 of this output tile has landed (3 regions in flight)
+    PP_BAR();
+    if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      // P1
+      PP_READ_A(buf, 0);
+      PP_READ_B(buf, 1, fb0);
+      if (kt + 1 < nk) issue(3, kt + 1);
+      lgkm0();
+      PP_BAR();
+      PP_MMA(0, 0, fb0);
+      PP_BAR();
+      // P2
+      PP_READ_B(buf, 2, fb1);
+      if (kt + 2 < nk) issue(0, kt + 2);
+      lgkm0();
+      PP_BAR();
+      PP_MMA(0, 1, fb1);
+      PP_BAR();
+      // P3
+      PP_READ_A(buf, 3);
+      if (kt + 2 < nk) issue(1, kt + 2);
+      lgkm0();
+      PP_BAR();
+      PP_MMA(2, 1, fb1);
+      PP_BAR();
+      // P4
+      if (kt + 2 < nk) { issue(2, kt + 2); wait_vmcnt<6>(); } else { wait_vmcnt<0>(); }
+      PP_BAR();
+      PP_MMA(2, 0, fb0);
+      PP_BAR();
+    }
+    if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
+    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
+    t += step;
+    const bool more = t < tend;
+    if (more) { set_tile(t); prologue(); }        // ring is free: request the next tile before the epilogue
+    // eight 16-row passes, expanded by hand: a loop here makes the compiler index acc[] dynamically
+    // (= the whole accumulator goes through scratch)
+#define PP_EPI(mi_, half_)                                                                              \
+    {                                                                                                   \
+      const int col = lane & 31, rhalf = (lane >> 5) * 4;                                               \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)    \
+          stg[((r & 3) + 8 * (r >> 2) + rhalf) * PP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r]; \
+      lgkm0();                                                                                          \
+      __builtin_amdgcn_wave_barrier();                                                                  \
+      epilogue<bf16raw, 16, 2, PP_STG_LD>(ep, stg, em0 + (mi_) * 32 + (half_) * 16, en0, lane);         \
+      lgkm0();                                                                                          \
+      __builtin_amdgcn_wave_barrier();                                                                  \
+    }
+    PP_EPI(0, 0) PP_EPI(0, 1) PP_EPI(1, 0) PP_EPI(1, 1) PP_EPI(2, 0) PP_EPI(2, 1) PP_EPI(3, 0) PP_EPI(3, 1)
+#undef PP_EPI
+    if (!more) break;
+  }
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MMA
+#undef PP_BAR
+}
+
+static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        PP_LDS_BYTES);
+    attr_set = true;
+  }
+  const int tiles_m = cdiv(d->M, PP_BM), tiles_n = cdiv(d->N, PP_BN);
+  // estimated time of one tile in 10-ns ticks of the constant 100 MHz clock (1.5 us per K tile + 6 us)
+  const char* sk = getenv("VTX_GEMM_PP_SKEW");
+  const int tile_ticks = (int)((sk ? atof(sk) : 1.0) * (150 * (d->K / PP_BK) + 600));
+  const char* gs = getenv("VTX_GEMM_PP_GRID");
+  const int grid = gs ? atoi(gs) : PP_GRID;
+  hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel, dim3(grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
+                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, ep);
+  return check_launch("gemm_nt_pp");
 }
 
 // ------------------------------------------------------------------ fp32 kernel
@@ -472,11 +687,12 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   if (d->dtype == VTX_BF16) {
     const size_t lds = STAGE_BYTES > 4 * BM * BK16 * 2 ? STAGE_BYTES : 4 * BM * BK16 * 2;
     const char* nodma = getenv("VTX_GEMM_NODMA");
-    const char* kv = getenv("VTX_GEMM_NT");             // tuning override: dma2 | ring128x3 | ring128x4k32 | ring256x3 | ring256x3k32 | ring256x4k32
+    const char* kv = getenv("VTX_GEMM_NT");             // tuning override: pp256 | dma2 | ring128x3 | ring128x4k32 | ring256x3 | ring256x3k32 | ring256x4k32
     const bool dma_ok = d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0);
     // default (measured, tools/kernel_bench.py): the 256x128 ring with BK=32 -- 72 KB of LDS, two co-resident
     // workgroups per CU whose prologue / epilogue overlap each other's main loop
-    std::string variant = kv ? kv : (d->M >= 1024 ? "ring256x3k32" : "dma2");
+    std::string variant = kv ? kv : (d->M >= 2048 ? "pp256" : d->M >= 1024 ? "ring256x3k32" : "dma2");
+    if (dma_ok && d->K / BK16 >= 2 && variant == "pp256") return launch_pp(d, ep, st);
     if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3") return launch_ring<4, 3, 64>(d, ep, st);
     if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3k32") return launch_ring<4, 3, 32>(d, ep, st);
     if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x4k32") return launch_ring<4, 4, 32>(d, ep, st);
