@@ -175,7 +175,7 @@ def test_gemm_tn(dtype, M, N1, N2, monkeypatch):
     from vtx import ops
     A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
     ref = q(A, dtype).t() @ q(Bm, dtype)
-    for safe, nodma, tnv in ([('0', '0', 'ring'), ('0', '0', 'dma2'), ('0', '1', 'ring'), ('1', '1', 'ring')]
+    for safe, nodma, tnv in ([('0', '0', 'pp256'), ('0', '0', 'ring'), ('0', '0', 'dma2'), ('0', '1', 'ring'), ('1', '1', 'ring')]
                              if dtype == torch.bfloat16 else [('0', '0', 'ring')]):
         monkeypatch.setenv('VTX_TN_SAFE', safe)
         monkeypatch.setenv('VTX_GEMM_NODMA', nodma)
@@ -209,6 +209,14 @@ def test_gemm_tn_rowmap_and_colsum(dtype):
     C3, cs3 = ops.gemm_tn(dev(A3, dtype), dev(B3, dtype), 5000, 216, 768, want_colsum=True)
     check(f'gemm_tn fused colsum N1 tail {dtype}', cs3.cpu(), q(A3, dtype).sum(0), 1e-3)
     check(f'gemm_tn N1 tail {dtype}', C3.cpu(), q(A3, dtype).t() @ q(B3, dtype), 2e-3)
+    # token-row maps through the 256x256 ping-pong kernel (M >= 4096, N1 and N2 multiples of 256)
+    Bp, Np = 4, 1570
+    Xp, Yp = rnd(Bp, 1 + Np, 256, seed=11), rnd(Bp, 1 + Np, 512, seed=12)
+    tmp_ = ops.tokmap(Np)
+    refp = q(Xp, dtype)[:, 1:].reshape(Bp * Np, 256).t() @ q(Yp, dtype)[:, 1:].reshape(Bp * Np, 512)
+    Cp, csp = ops.gemm_tn(dev(Xp, dtype), dev(Yp, dtype), Bp * Np, 256, 512, amap=tmp_, bmap=tmp_, want_colsum=True)
+    check(f'gemm_tn pp rowmaps {dtype}', Cp.cpu(), refp, 2e-3)
+    check(f'gemm_tn pp rowmaps colsum {dtype}', csp.cpu(), q(Xp, dtype)[:, 1:].reshape(-1, 256).sum(0), 1e-3)
     big = rnd(5000, 2304, seed=3)
     cs = ops.colsum(dev(big, dtype), 5000, 2304)
     check(f'colsum big {dtype}', cs.cpu(), q(big, dtype).sum(0), 1e-3)

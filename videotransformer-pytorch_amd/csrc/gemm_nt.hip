@@ -353,9 +353,8 @@ static int launch_ring(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
 // Phase q of tile t issues region (A1,t+1) / (A0,t+2) / (B0,t+2) / (B1,t+2) for q = 1..4.
 //   WAR: the overwritten copy was last read >= 1 full phase earlier and every load section retires
 //        its reads (lgkmcnt(0)) BEFORE its barrier, so both groups are past them.
-//   RAW: P4 waits vmcnt(6) (everything but the 3 youngest regions = all of tile t+1 has landed),
-//        then the barrier publishes it; tile t+1 is first read one phase later.
-// Past the last tile the DMA source is clamped to the last tile (the regions written are never read).
+//   RAW: the load section BEFORE the phase that reads a region waits for it with a counted vmcnt that
+//        leaves every younger region (up to 5 = 80 KB per CU) in flight, then its barrier publishes it.
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_THREADS = 512;
 constexpr int PP_REGION = 128 * PP_BK;          // elements per region
 constexpr int PP_BUF = 4 * PP_REGION;           // elements per K-tile buffer: [A0 | B0 | B1 | A1]
@@ -470,35 +469,38 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 fa[2][4], fb0[4], fb1[4];
-    wait_vmcnt<6>();                              // tile 0 of this output tile has landed (3 regions in flight)
+    // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
+    // younger request in flight (2 DMA instructions per region; issue order A0 B0 B1 A1 per K tile).
+    wait_vmcnt<10>();                             // A0(0), B0(0) landed; B1(0) A1(0) A0(1) B0(1) B1(1) in flight
     PP_BAR();
     if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
-      // P1
+      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+      // P1: reads A0, B0; P2 will read B1(kt)
       PP_READ_A(buf, 0);
       PP_READ_B(buf, 1, fb0);
-      if (kt + 1 < nk) issue(3, kt + 1);
+      if (n1) { issue(3, kt + 1); wait_vmcnt<10>(); } else { wait_vmcnt<2>(); }
       lgkm0();
       PP_BAR();
       PP_MMA(0, 0, fb0);
       PP_BAR();
-      // P2
+      // P2: reads B1; P3 will read A1(kt)
       PP_READ_B(buf, 2, fb1);
-      if (kt + 2 < nk) issue(0, kt + 2);
+      if (n2) { issue(0, kt + 2); wait_vmcnt<10>(); } else if (n1) { wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
       lgkm0();
       PP_BAR();
       PP_MMA(0, 1, fb1);
       PP_BAR();
-      // P3
+      // P3: reads A1
       PP_READ_A(buf, 3);
-      if (kt + 2 < nk) issue(1, kt + 2);
+      if (n2) issue(1, kt + 2);
       lgkm0();
       PP_BAR();
       PP_MMA(2, 1, fb1);
       PP_BAR();
-      // P4
-      if (kt + 2 < nk) { issue(2, kt + 2); wait_vmcnt<6>(); } else { wait_vmcnt<0>(); }
+      // P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1)
+      if (n2) { issue(2, kt + 2); wait_vmcnt<10>(); } else if (n1) { wait_vmcnt<4>(); }
       PP_BAR();
       PP_MMA(2, 0, fb0);
       PP_BAR();

@@ -350,8 +350,9 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int split = blockIdx.x / tiles12;
-  const int tile = blockIdx.x - split * tiles12;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);          // split-major runs per XCD (see the pp kernel)
+  const int split = bid / tiles12;
+  const int tile = bid - split * tiles12;
   const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
   const int r0 = t1 * 256, c0 = t2 * 128;
   const int m_begin = split * m_per_split;
@@ -518,6 +519,265 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
   }
 }
 
+// ---- bf16, 256x256 output tile, two staggered wave groups (mirror of gemm_nt's pp kernel) -------
+// out[256 n1][256 n2] partial over a span of token rows.  8 waves as 2(n1) x 4(n2), 128x64 per wave,
+// groups wr = wave>>2 one barrier apart; a K tile = 64 token rows in four phases
+// (A0 x B0 | A0 x B1 | A1 x B1 | A1 x B0, 8 MFMAs each).  LDS regions are [64 token rows][128 columns]
+// (A0 = columns wr*128 + [0,64) of both wave rows, A1 the other halves, B0 = columns wc*64 + [0,32) of
+// all four wave columns, B1 the other halves), 16-B chunks XOR-swizzled with (row&3)<<2 on the DMA
+// source side; fragments come out through `ds_read_b64_tr_b16` (the reduction index is the LDS row).
+// Same region-wise lookahead / vmcnt / barrier protocol as gemm_nt_bf16_pp_kernel (see there).
+// A ragged last tile is fetched with clamped row indices and the rows beyond the span are zeroed in
+// LDS by the wave that fetched them (right after its vmcnt wait, before the publishing barrier).
+// Bias gradient: workgroups of column tile 0 also sum the A regions over the token rows (two
+// ds_read_b128 + 16 adds per thread and region, in the load sections).
+constexpr int TP_BK = 64, TP_THREADS = 512;
+constexpr int TP_REGION = TP_BK * 128;           // elements
+constexpr int TP_BUF = 4 * TP_REGION;            // [A0 | B0 | B1 | A1]
+constexpr int TP_RING_BYTES = 2 * TP_BUF * 2;    // 131072
+constexpr int TP_STG_LD = 64;
+constexpr int TP_LDS_BYTES = TP_RING_BYTES + 8 * 16 * TP_STG_LD * 4;
+
+__device__ inline void tp_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
+    int M, int m_per_split, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // XCD-aware order: the tiles of one split read the same token rows, so give every XCD a contiguous
+  // run of the split-major work list (its L2 then serves each A / B row to all the tiles that need it;
+  // round-robin placement re-fetches every panel once per XCD: 1.85 GB instead of 0.39 GB at 768x3072)
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid / tiles12;
+  const int tile = bid - split * tiles12;
+  const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+  const int r0 = t1 * 256, c0 = t2 * 256;
+  const int m_begin = split * m_per_split;
+  const int m_end = (split == (int)(gridDim.x / tiles12) - 1) ? M : m_begin + m_per_split;   // last split: + remainder
+  const int span = m_end - m_begin;
+  const int nk = (span + TP_BK - 1) / TP_BK;      // >= 2 (host guarantees m_per_split >= 128)
+  const int last_valid = span - (nk - 1) * TP_BK; // rows of the last tile that are inside the span
+
+  // DMA: piece p (= 4 token rows x 256 B) of every region; this wave owns pieces 2*wave, 2*wave+1.
+  // lane -> row 4p + lane/16, physical chunk lane%16, logical chunk = physical ^ ((row&3)<<2).
+  int prow[2], acol[2][2], bcol[2][2];            // [piece][region half]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    prow[j] = (wave * 2 + j) * 4 + (lane >> 4);
+    const int rc = ((lane & 15) ^ ((prow[j] & 3) << 2)) * 8;        // region column 0..127
+    acol[j][0] = r0 + (rc >> 6) * 128 + (rc & 63); acol[j][1] = acol[j][0] + 64;
+    bcol[j][0] = c0 + (rc >> 5) * 64 + (rc & 31); bcol[j][1] = bcol[j][0] + 32;
+  }
+  // Row maps without a division per DMA: phys(m) = base + m + (m / grp) * skip.  Every region kind is
+  // requested for K tiles 0, 1, 2, ... in order, so keep (quotient, remainder) of its next tile's
+  // first row in SGPRs and step them by 64 (grp > 64 or grp == 0 is checked by the host).
+  int tq[4], trm[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = (k == 0 || k == 3) ? amap.grp : bmap.grp;
+    tq[k] = g > 0 ? m_begin / g : 0;
+    trm[k] = g > 0 ? m_begin - tq[k] * g : 0;
+  }
+  auto issue = [&](int kind, int kt) {            // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+    bf16raw* dst = lds + (kt & 1) * TP_BUF + kind * TP_REGION + wave * 1024;
+    const bool isA = kind == 0 || kind == 3;
+    const vtx_rowmap& mp = isA ? amap : bmap;
+    const int mt = m_begin + kt * TP_BK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int off = prow[j];
+      if (mt + off >= M) off = M - 1 - mt;        // clamp to the last valid row (zeroed in LDS afterwards)
+      const int qq = tq[kind] + ((mp.grp > 0 && trm[kind] + off >= mp.grp) ? 1 : 0);
+      const long phys = (long)mp.base + mt + off + (long)qq * mp.skip;
+      const bf16raw* src = isA ? A + phys * lda + acol[j][kind == 3] : B + phys * ldb + bcol[j][kind == 2];
+      tn_dma16(src, dst + j * 512);
+    }
+    trm[kind] += TP_BK;
+    if (mp.grp > 0 && trm[kind] >= mp.grp) { trm[kind] -= mp.grp; ++tq[kind]; }
+  };
+  auto zero_tail = [&](int kt) {                  // rows >= last_valid of tile kt (this wave's own pieces)
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (prow[j] >= last_valid)
+          *reinterpret_cast<uint4*>(lds + (kt & 1) * TP_BUF + kind * TP_REGION + wave * 1024 + j * 512 + lane * 8) =
+              make_uint4(0, 0, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed fragment addressing inside a region: token row ks*16 + tr_row (+4), column c
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_sw = ((lane & 15) >> 2) << 2;
+  const int cl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);   // column of this lane inside a 32-column group
+  int fa_off[2], fb_off;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = wr * 64 + i * 32 + cl;
+    fa_off[i] = tr_row * 128 + (((c >> 3) ^ tr_sw) << 3) + (c & 7);
+  }
+  {
+    const int c = wc * 32 + cl;
+    fb_off = tr_row * 128 + (((c >> 3) ^ tr_sw) << 3) + (c & 7);
+  }
+  // column sums: thread -> physical chunk tid&15 of rows tid>>4 and (tid>>4)+32
+  const bool do_cs = out.cslab != nullptr && t2 == 0;
+  const int cs_row = tid >> 4, cs_pc = tid & 15;
+  float cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TP_COLSUM(buf_, kind_, cs_)                                                                      \
+  if (do_cs) {                                                                                           \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                   \
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + (buf_) * TP_BUF + (kind_) * TP_REGION +      \
+                                                      (cs_row + 32 * it) * 128 + cs_pc * 8);             \
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};                                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        cs_[2 * j] += __uint_as_float(w[j] << 16);                                                       \
+        cs_[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);                                           \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+#define TP_TR(ptr_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr_))
+#define TP_READ_A(buf_, kind_)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {       \
+    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 128 + fa_off[i];         \
+    union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
+    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 128);                                                  \
+    fa[i][ks] = u_.v;                                                                                    \
+  }
+#define TP_READ_B(buf_, kind_, fb_)                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
+    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 128 + fb_off;            \
+    union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
+    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 128);                                                  \
+    fb_[ks] = u_.v;                                                                                      \
+  }
+#define TP_MMA(i0_, j_, fb_)                                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int i = 0; i < 2; ++i)         \
+      acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+#define TP_BAR() __builtin_amdgcn_s_barrier()
+
+  bf16x8 fa[2][4], fb0[4], fb1[4];
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+  issue(0, 1); issue(1, 1); issue(2, 1);
+  // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
+  // younger request in flight (2 DMA instructions per region; the issue order is A0 B0 B1 A1 per tile).
+  tn_wait_vmcnt<10>();                            // A0(0), B0(0) landed; B1(0) A1(0) A0(1) B0(1) B1(1) in flight
+  TP_BAR();
+  if (wr == 1) TP_BAR();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // P1: reads A0, B0; P2 will read B1(kt)
+    TP_READ_A(buf, 0);
+    TP_READ_B(buf, 1, fb0);
+    TP_COLSUM(buf, 0, cs0);
+    if (n1) { issue(3, kt + 1); tn_wait_vmcnt<10>(); } else { tn_wait_vmcnt<2>(); }
+    tp_lgkm0();
+    TP_BAR();
+    TP_MMA(0, 0, fb0);
+    TP_BAR();
+    // P2: reads B1; P3 will read A1(kt)
+    TP_READ_B(buf, 2, fb1);
+    if (n2) { issue(0, kt + 2); tn_wait_vmcnt<10>(); } else if (n1) { tn_wait_vmcnt<8>(); } else { tn_wait_vmcnt<0>(); }
+    tp_lgkm0();
+    TP_BAR();
+    TP_MMA(0, 1, fb1);
+    TP_BAR();
+    // P3: reads A1
+    TP_READ_A(buf, 3);
+    TP_COLSUM(buf, 3, cs1);
+    if (n2) issue(1, kt + 2);
+    tp_lgkm0();
+    TP_BAR();
+    TP_MMA(2, 1, fb1);
+    TP_BAR();
+    // P4: no reads; P1 of the next tile will read A0(kt+1), B0(kt+1)
+    if (n2) {
+      issue(2, kt + 2);
+      tn_wait_vmcnt<10>();
+    } else if (n1) {
+      if (last_valid < TP_BK) { tn_wait_vmcnt<0>(); zero_tail(kt + 1); tp_lgkm0(); } else { tn_wait_vmcnt<4>(); }
+    }
+    TP_BAR();
+    TP_MMA(2, 0, fb0);
+    TP_BAR();
+  }
+  if (wr == 0) TP_BAR();
+#undef TP_COLSUM
+#undef TP_TR
+#undef TP_READ_A
+#undef TP_READ_B
+#undef TP_MMA
+#undef TP_BAR
+  if (do_cs) {
+    // logical chunk of this thread = cs_pc ^ ((cs_row&3)<<2) (rows cs_row and cs_row+32 share row&3);
+    // region column rc -> tile column: A0: (rc>>6)*128 + (rc&63), A1: +64
+    float* red = reinterpret_cast<float*>(smem);            // [32][256] floats = 32 KB (ring is free)
+    const int rc = (cs_pc ^ ((cs_row & 3) << 2)) * 8;
+    const int tc = (rc >> 6) * 128 + (rc & 63);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[cs_row * 256 + tc + j] = cs0[j];
+      red[cs_row * 256 + tc + 64 + j] = cs1[j];
+    }
+    __syncthreads();
+    if (tid < 256 && r0 + tid < out.N1) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) a += red[r * 256 + tid];
+      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
+    }
+    __syncthreads();
+  }
+  float* stg = reinterpret_cast<float*>(smem + TP_RING_BYTES) + wave * 16 * TP_STG_LD;
+  float* dst = out.slab + (long)split * out.slab_stride;
+#define TP_EPI(mi_, half_)                                                                               \
+  {                                                                                                      \
+    const int col = lane & 31, rhalf = (lane >> 5) * 4;                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)       \
+        stg[((r & 3) + 8 * (r >> 2) + rhalf) * TP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r]; \
+    tp_lgkm0();                                                                                          \
+    __builtin_amdgcn_wave_barrier();                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                      \
+      const int rw = e * 8 + (lane >> 3);                                                                \
+      const int r = r0 + wr * 128 + (mi_) * 32 + (half_) * 16 + rw, c = c0 + wc * 64 + (lane & 7) * 8;   \
+      if (r < out.N1 && c < out.N2) {                                                                    \
+        const float* sp = stg + rw * TP_STG_LD + (lane & 7) * 8;                                         \
+        float* d = dst + (long)r * out.N2 + c;                                                           \
+        *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(sp);                            \
+        *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(sp + 4);                    \
+      }                                                                                                  \
+    }                                                                                                    \
+    tp_lgkm0();                                                                                          \
+    __builtin_amdgcn_wave_barrier();                                                                     \
+  }
+  TP_EPI(0, 0) TP_EPI(0, 1) TP_EPI(1, 0) TP_EPI(1, 1) TP_EPI(2, 0) TP_EPI(2, 1) TP_EPI(3, 0) TP_EPI(3, 1)
+#undef TP_EPI
+}
+
+static int tp_splits(int M, int N1, int N2) {
+  const int tiles = cdiv(N1, 256) * cdiv(N2, 256);
+  int s = 256 / tiles;                          // one workgroup per CU
+  const int max_s = M / 128;                    // every split spans >= 2 K tiles
+  if (s > max_s) s = max_s;
+  return s < 1 ? 1 : s;
+}
+static bool tp_eligible(int M, int N1, int N2) { return M >= 4096 && N1 % 256 == 0 && N2 % 256 == 0; }
+static bool tp_map_ok(const vtx_rowmap& m) { return m.grp == 0 || m.grp > TP_BK; }
+
 __global__ __launch_bounds__(NT_THREADS) void gemm_tn_f32_kernel(
     int M, int m_per_split, const float* __restrict__ A, long lda, vtx_rowmap amap,
     const float* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
@@ -669,7 +929,8 @@ static int colsum_blocks(int M) {
 using namespace vtx;
 
 extern "C" size_t vtx_gemm_tn_workspace(int M, int N1, int N2) {
-  const size_t s = (size_t)tn_splits(M, N1, N2);
+  size_t s = (size_t)tn_splits(M, N1, N2);
+  if (tp_eligible(M, N1, N2) && (size_t)tp_splits(M, N1, N2) > s) s = (size_t)tp_splits(M, N1, N2);
   return s * (size_t)N1 * (size_t)N2 * sizeof(float) + s * (size_t)N1 * sizeof(float);   // slabs + column-sum slabs
 }
 
@@ -703,8 +964,29 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     const char* safe_env = getenv("VTX_TN_SAFE");   // diagnostic path, read per call
     const bool safe = safe_env && atoi(safe_env) != 0;
     const char* nodma = getenv("VTX_GEMM_NODMA");
-    const char* tnv = getenv("VTX_GEMM_TN");            // tuning override: ring | dma2
+    const char* tnv = getenv("VTX_GEMM_TN");            // tuning override: pp256 | ring | dma2
     const bool want_ring = !(tnv && std::string(tnv) == "dma2") && d->M >= 1024;
+    const bool want_pp = !(tnv && std::string(tnv) != "pp256") && tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
+    if (!safe && !(nodma && atoi(nodma) != 0) && want_pp) {
+      const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
+      const int s_p = tp_splits(d->M, d->N1, d->N2);
+      const int m_per_p = (d->M / s_p) / TP_BK * TP_BK;        // the last split also takes the remainder
+      const int s_eff = s_p;
+      static bool attr_set_p = false;
+      if (!attr_set_p) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES);
+        attr_set_p = true;
+      }
+      if (m_per_p >= 2 * TP_BK) {
+        hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(t1p * t2p * s_eff), dim3(TP_THREADS), TP_LDS_BYTES, st, d->M, m_per_p,
+                           (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out);
+        int rc_p = check_launch("gemm_tn_pp");
+        if (rc_p) return rc_p;
+        if (!d->colsum) return launch_reduce_partials(out.slab, s_eff, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
+        return launch_reduce_partials(out.slab, s_eff, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
+                                      d->colsum, w_elems, d->colsum_accumulate);
+      }
+    }
     if (!safe && !(nodma && atoi(nodma) != 0) && want_ring) {
       const int tiles1r = cdiv(d->N1, 256);
       int s_r = cdiv(512, tiles1r * tiles2);
