@@ -216,7 +216,7 @@ def main():
             'model_tflops_per_gpu': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12, 2),
             'mfma_frac_whole_step': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12 / PEAK_BF16, 4),
             'final_loss': round(final_loss, 4),
-            'roofline': {'kernel': 'gemm_nt_bf16_ring_kernel<4,3,32> (all vtx_gemm_nt launches)' if args.precision == 'bf16' else 'gemm_nt_f32_kernel',
+            'roofline': {'kernel': 'gemm_nt_bf16_pp_kernel (all vtx_gemm_nt launches)' if args.precision == 'bf16' else 'gemm_nt_f32_kernel',
                          'bound': 'mfma', 'achieved': round(achieved, 2),
                          'peak': PEAK_BF16 if args.precision == 'bf16' else 157.3, 'unit': 'TFLOP/s',
                          'frac': round(achieved / (PEAK_BF16 if args.precision == 'bf16' else 157.3), 4),

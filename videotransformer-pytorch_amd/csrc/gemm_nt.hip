@@ -448,10 +448,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #define PP_READ_B(buf_, kind_, fb_)                                                                    \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
       fb_[ks] = *reinterpret_cast<const bf16x8*>(lds + (buf_) * PP_BUF + (kind_) * PP_REGION + b_grp + fr[ks]);
-#define PP_MMA(i0_, j_, fb_)                                                                           \
+#define PP_MMA(i0_, j_, fb_, ISSUE_)                                                                   \
   __builtin_amdgcn_s_setprio(1);                                                                       \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int i = 0; i < 2; ++i)       \
-      acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+        acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
+    if (ks == 0) { __builtin_amdgcn_sched_barrier(0); ISSUE_; __builtin_amdgcn_sched_barrier(0); }     \
+  }                                                                                                    \
   __builtin_amdgcn_s_setprio(0);
 #define PP_BAR() __builtin_amdgcn_s_barrier()
 
@@ -477,32 +480,33 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
       const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+      // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section):
+      // inside a load section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
       // P1: reads A0, B0; P2 will read B1(kt)
       PP_READ_A(buf, 0);
       PP_READ_B(buf, 1, fb0);
-      if (n1) { issue(3, kt + 1); wait_vmcnt<10>(); } else { wait_vmcnt<2>(); }
+      if (n1) wait_vmcnt<8>(); else wait_vmcnt<2>();
       lgkm0();
       PP_BAR();
-      PP_MMA(0, 0, fb0);
+      PP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));
       PP_BAR();
       // P2: reads B1; P3 will read A1(kt)
       PP_READ_B(buf, 2, fb1);
-      if (n2) { issue(0, kt + 2); wait_vmcnt<10>(); } else if (n1) { wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
+      if (n1) wait_vmcnt<8>(); else wait_vmcnt<0>();
       lgkm0();
       PP_BAR();
-      PP_MMA(0, 1, fb1);
+      PP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));
       PP_BAR();
       // P3: reads A1
       PP_READ_A(buf, 3);
-      if (n2) issue(1, kt + 2);
       lgkm0();
       PP_BAR();
-      PP_MMA(2, 1, fb1);
+      PP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));
       PP_BAR();
       // P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1)
-      if (n2) { issue(2, kt + 2); wait_vmcnt<10>(); } else if (n1) { wait_vmcnt<4>(); }
+      if (n2) wait_vmcnt<8>(); else if (n1) wait_vmcnt<4>();
       PP_BAR();
-      PP_MMA(2, 0, fb0);
+      PP_MMA(2, 0, fb0, if (n2) issue(2, kt + 2));
       PP_BAR();
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read

@@ -662,10 +662,13 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 128);                                                  \
     fb_[ks] = u_.v;                                                                                      \
   }
-#define TP_MMA(i0_, j_, fb_)                                                                             \
+#define TP_MMA(i0_, j_, fb_, ISSUE_)                                                                     \
   __builtin_amdgcn_s_setprio(1);                                                                         \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int i = 0; i < 2; ++i)         \
-      acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+        acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
+    if (ks == 0) { __builtin_amdgcn_sched_barrier(0); ISSUE_; __builtin_amdgcn_sched_barrier(0); }       \
+  }                                                                                                      \
   __builtin_amdgcn_s_setprio(0);
 #define TP_BAR() __builtin_amdgcn_s_barrier()
 
@@ -680,39 +683,38 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // (DMA requests are issued in the shadow of the MFMAs, see gemm_nt_bf16_pp_kernel)
     // P1: reads A0, B0; P2 will read B1(kt)
     TP_READ_A(buf, 0);
     TP_READ_B(buf, 1, fb0);
     TP_COLSUM(buf, 0, cs0);
-    if (n1) { issue(3, kt + 1); tn_wait_vmcnt<10>(); } else { tn_wait_vmcnt<2>(); }
+    if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<2>();
     tp_lgkm0();
     TP_BAR();
-    TP_MMA(0, 0, fb0);
+    TP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));
     TP_BAR();
     // P2: reads B1; P3 will read A1(kt)
     TP_READ_B(buf, 2, fb1);
-    if (n2) { issue(0, kt + 2); tn_wait_vmcnt<10>(); } else if (n1) { tn_wait_vmcnt<8>(); } else { tn_wait_vmcnt<0>(); }
+    if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<0>();
     tp_lgkm0();
     TP_BAR();
-    TP_MMA(0, 1, fb1);
+    TP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));
     TP_BAR();
     // P3: reads A1
     TP_READ_A(buf, 3);
     TP_COLSUM(buf, 3, cs1);
-    if (n2) issue(1, kt + 2);
     tp_lgkm0();
     TP_BAR();
-    TP_MMA(2, 1, fb1);
+    TP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));
     TP_BAR();
     // P4: no reads; P1 of the next tile will read A0(kt+1), B0(kt+1)
     if (n2) {
-      issue(2, kt + 2);
-      tn_wait_vmcnt<10>();
+      tn_wait_vmcnt<8>();
     } else if (n1) {
       if (last_valid < TP_BK) { tn_wait_vmcnt<0>(); zero_tail(kt + 1); tp_lgkm0(); } else { tn_wait_vmcnt<4>(); }
     }
     TP_BAR();
-    TP_MMA(2, 0, fb0);
+    TP_MMA(2, 0, fb0, if (n2) issue(2, kt + 2));
     TP_BAR();
   }
   if (wr == 0) TP_BAR();
