@@ -74,7 +74,7 @@ int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, vtx
  * patch gather (:116-126,142,146), MaskFeat decoder_pred
  * (video_transformer.py:855,878).
  * Epilogue order:  v = acc (+bias[n]);  act GELU(erf): C2 = v, v = gelu(v);
- *                  v *= gelu'(dgelu_in[m][n]);  v *= row_scale[idx(m)];
+ *                  v *= gelu'(dgelu_in[m][n]);  v *= row_scale[idx(m)];  v += bias2[n];
  *                  v += R[rmap(m) or m % r_period][n];  C[cmap(m)][n] = v.
  * Rows m >= split_row (if split_row > 0) are stored to Csplit[m - split_row]
  * with bias/act/scale applied but no residual (the per-frame cls rows of the
@@ -93,6 +93,7 @@ typedef struct {
   int rs_d1, rs_m1, rs_d2, rs_m2;     /* idx(m) = (m / rs_d1) * rs_m1 + (m % rs_d2) * rs_m2 */
   const void* R; long ldr; vtx_rowmap rmap; int r_period; /* residual; r_period>0: row m % r_period */
   int split_row; void* Csplit; long ldsplit;
+  const float* bias2;                 /* [N] added AFTER the row scale (a bias behind DropPath), or NULL */
 } vtx_gemm_desc;
 int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream);
 

@@ -670,6 +670,7 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C) && d->lda % vec == 0 && d->ldb % vec == 0 &&
                   d->ldc % vec == 0, VTX_EALIGN, "gemm_nt: operands must be 16-byte aligned");
   VTX_REQUIRE(!d->bias || aligned16(d->bias), VTX_EALIGN, "gemm_nt: bias not aligned");
+  VTX_REQUIRE(!d->bias2 || aligned16(d->bias2), VTX_EALIGN, "gemm_nt: bias2 not aligned");
   VTX_REQUIRE(!d->R || (aligned16(d->R) && d->ldr % vec == 0), VTX_EALIGN, "gemm_nt: residual not aligned");
   VTX_REQUIRE(!(d->act == 1 && d->C2) || (aligned16(d->C2) && d->ldc2 % vec == 0), VTX_EALIGN, "gemm_nt: C2 not aligned");
   VTX_REQUIRE(!d->dgelu_in || (aligned16(d->dgelu_in) && d->ld_dgelu % vec == 0), VTX_EALIGN, "gemm_nt: dgelu_in not aligned");
@@ -686,6 +687,7 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   ep.row_scale = d->row_scale; ep.rs_d1 = d->rs_d1; ep.rs_m1 = d->rs_m1; ep.rs_d2 = d->rs_d2; ep.rs_m2 = d->rs_m2;
   ep.R = d->R; ep.ldr = d->ldr; ep.rmap = d->rmap; ep.r_period = d->r_period;
   ep.split_row = d->split_row; ep.Csplit = d->Csplit; ep.ldsplit = d->ldsplit;
+  ep.bias2 = d->bias2;
 
   const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
   dim3 grid(tiles_m * tiles_n), block(NT_THREADS);

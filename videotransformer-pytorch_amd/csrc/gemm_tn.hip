@@ -523,8 +523,8 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
 // out[256 n1][256 n2] partial over a span of token rows.  8 waves as 2(n1) x 4(n2), 128x64 per wave,
 // groups wr = wave>>2 one barrier apart; a K tile = 64 token rows in four phases
 // (A0 x B0 | A0 x B1 | A1 x B1 | A1 x B0, 8 MFMAs each).  LDS regions are [64 token rows][128 columns]
-// (A0 = columns wr*128 + [0,64) of both wave rows, A1 the other halves, B0 = columns wc*64 + [0,32) of
-// all four wave columns, B1 the other halves), 16-B chunks XOR-swizzled with (row&3)<<2 on the DMA
+// (A0 = columns wr*128 + [0,64) of both wave rows, A1 the other halves; B0 = columns [0,128), B1 = columns
+// [128,256) of the tile, wave column wc owning wc*32 + [0,32) of each: every DMA row segment is whole 128-B lines), 16-B chunks XOR-swizzled with (row&3)<<2 on the DMA
 // source side; fragments come out through `ds_read_b64_tr_b16` (the reduction index is the LDS row).
 // Same region-wise lookahead / vmcnt / barrier protocol as gemm_nt_bf16_pp_kernel (see there).
 // A ragged last tile is fetched with clamped row indices and the rows beyond the span are zeroed in
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     prow[j] = (wave * 2 + j) * 4 + (lane >> 4);
     const int rc = ((lane & 15) ^ ((prow[j] & 3) << 2)) * 8;        // region column 0..127
     acol[j][0] = r0 + (rc >> 6) * 128 + (rc & 63); acol[j][1] = acol[j][0] + 64;
-    bcol[j][0] = c0 + (rc >> 5) * 64 + (rc & 31); bcol[j][1] = bcol[j][0] + 32;
+    bcol[j][0] = c0 + rc; bcol[j][1] = bcol[j][0] + 128;   // whole 128-B lines: wave wc owns columns wc*32+[0,32) of each half
   }
   // Row maps without a division per DMA: phys(m) = base + m + (m / grp) * skip.  Every region kind is
   // requested for K tiles 0, 1, 2, ... in order, so keep (quotient, remainder) of its next tile's
@@ -755,7 +755,8 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     __builtin_amdgcn_wave_barrier();                                                                     \
     _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                      \
       const int rw = e * 8 + (lane >> 3);                                                                \
-      const int r = r0 + wr * 128 + (mi_) * 32 + (half_) * 16 + rw, c = c0 + wc * 64 + (lane & 7) * 8;   \
+      const int r = r0 + wr * 128 + (mi_) * 32 + (half_) * 16 + rw;                                      \
+      const int c = c0 + ((lane & 7) >> 2) * 128 + wc * 32 + (lane & 3) * 8;                             \
       if (r < out.N1 && c < out.N2) {                                                                    \
         const float* sp = stg + rw * TP_STG_LD + (lane & 7) * 8;                                         \
         float* d = dst + (long)r * out.N2 + c;                                                           \

@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ('rs_d1', C.c_int), ('rs_m1', C.c_int), ('rs_d2', C.c_int), ('rs_m2', C.c_int),
         ('R', C.c_void_p), ('ldr', C.c_long), ('rmap', RowMap), ('r_period', C.c_int),
         ('split_row', C.c_int), ('Csplit', C.c_void_p), ('ldsplit', C.c_long),
+        ('bias2', C.c_void_p),
     ]
 
 

@@ -113,7 +113,7 @@ def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dre
 # ----------------------------------------------------------------------- GEMM
 def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=IDENT, bias=None, act=0,
             C2=None, dgelu_in=None, row_scale=None, rs=(1, 0, 1, 0), R=None, ldr=None, rmap=IDENT,
-            r_period=0, split_row=0, Csplit=None):
+            r_period=0, split_row=0, Csplit=None, bias2=None):
     """C = epilogue(A[M,K] @ B[N,K]^T); see vtx_gemm_nt in include/vtx.h."""
     need_cuda(A, B, Cout)
     if A.dtype != B.dtype or A.dtype != Cout.dtype:
@@ -129,6 +129,8 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
     d.row_scale = ptr(_f32(row_scale)); d.rs_d1, d.rs_m1, d.rs_d2, d.rs_m2 = [int(v) for v in rs]
     d.R = ptr(R); d.ldr = (N if ldr is None else ldr); d.rmap = rmap; d.r_period = int(r_period)
     d.split_row = int(split_row); d.Csplit = ptr(Csplit); d.ldsplit = N
+    b2 = _f32(bias2)
+    d.bias2 = ptr(b2)
     with _timed('gemm_nt', 2.0 * M * N * K):
         call('vtx_gemm_nt', C.byref(d), stream())
 
