@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='clips per GPU (weak scaling)')
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU (weak scaling)')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -102,6 +102,27 @@ def cpu_baseline(frames, steps=1):
             'sample': f'oracle/vt_oracle.py TimeSformer-B {frames}x224^2 fp32 train fwd+bwd, batch 1, '
                       f'{steps} timed steps after 1 warm-up'}
 
+
+
+def pmc_traffic_per_launch(B, args):
+    """HBM-side bytes per vtx_gemm_nt launch from the committed rocprofv3 PMC passes of THIS command
+    (profiles/round1_pmc_{FETCH,WRITE}_SIZE_b64.txt: separate --pmc passes, KB per dispatch summed over
+    the listed dispatches).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced
+    streams on gfx950; WRITE_SIZE is uncalibrated and taken as is.  None when the configuration differs
+    from the profiled one (the counters cannot be collected from inside the timed run)."""
+    if B != 64 or args.precision != 'bf16' or args.frames != 8:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot = 0.0
+    for name, mult in (('round1_pmc_FETCH_SIZE_b64.txt', 2.0), ('round1_pmc_WRITE_SIZE_b64.txt', 1.0)):
+        try:
+            for line in open(os.path.join(here, 'profiles', name)):
+                if 'gemm_nt_bf16_pp_kernel' in line:
+                    f = dict(kv.split('=') for kv in line.split() if '=' in kv)
+                    tot += mult * float(f['total']) * 1024.0 / float(f['rows'])
+        except (OSError, KeyError, ValueError):
+            return None
+    return round(tot, 0) if tot > 0 else None
 
 def main():
     args = parse()
@@ -220,7 +241,7 @@ def main():
                          'bound': 'mfma', 'achieved': round(achieved, 2),
                          'peak': PEAK_BF16 if args.precision == 'bf16' else 157.3, 'unit': 'TFLOP/s',
                          'frac': round(achieved / (PEAK_BF16 if args.precision == 'bf16' else 157.3), 4),
-                         'traffic': None, 'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
+                         'traffic': pmc_traffic_per_launch(B, args), 'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
                          'flops_per_launch_avg': round(flops / max(n, 1), 0)},
         }
         if breakdown is not None:

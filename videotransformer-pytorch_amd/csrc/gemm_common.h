@@ -131,7 +131,8 @@ __device__ inline void epilogue(const EpiParams& p, const float* stage, int m_ba
       float r8[UB][8];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const long rr = p.r_period > 0 ? (long)(ml[u] % p.r_period) : map_row(p.rmap, ml[u]);
+        // split rows take no residual: do not form their (out-of-range) residual address, read row 0
+        const long rr = split[u] ? 0 : (p.r_period > 0 ? (long)(ml[u] % p.r_period) : map_row(p.rmap, ml[u]));
         load8(reinterpret_cast<const T*>(p.R) + rr * p.ldr + n, r8[u]);
       }
 #pragma unroll

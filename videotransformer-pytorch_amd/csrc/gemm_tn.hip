@@ -522,9 +522,9 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
 // ---- bf16, 256x256 output tile, two staggered wave groups (mirror of gemm_nt's pp kernel) -------
 // out[256 n1][256 n2] partial over a span of token rows.  8 waves as 2(n1) x 4(n2), 128x64 per wave,
 // groups wr = wave>>2 one barrier apart; a K tile = 64 token rows in four phases
-// (A0 x B0 | A0 x B1 | A1 x B1 | A1 x B0, 8 MFMAs each).  LDS regions are [64 token rows][128 columns]
+// (A0 x B0 | A0 x B1 | A1 x B1 | A1 x B0, 8 MFMAs each).  LDS regions are 2 x [64 token rows][64 columns]
 // (A0 = columns wr*128 + [0,64) of both wave rows, A1 the other halves; B0 = columns [0,128), B1 = columns
-// [128,256) of the tile, wave column wc owning wc*32 + [0,32) of each: every DMA row segment is whole 128-B lines), 16-B chunks XOR-swizzled with (row&3)<<2 on the DMA
+// [128,256) of the tile, wave column wc owning wc*32 + [0,32) of each: every DMA row segment is whole 128-B lines), 16-B chunks XOR-swizzled with ((row>>1)&1)<<2 on the DMA
 // source side; fragments come out through `ds_read_b64_tr_b16` (the reduction index is the LDS row).
 // Same region-wise lookahead / vmcnt / barrier protocol as gemm_nt_bf16_pp_kernel (see there).
 // A ragged last tile is fetched with clamped row indices and the rows beyond the span are zeroed in
@@ -562,15 +562,19 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   const int nk = (span + TP_BK - 1) / TP_BK;      // >= 2 (host guarantees m_per_split >= 128)
   const int last_valid = span - (nk - 1) * TP_BK; // rows of the last tile that are inside the span
 
-  // DMA: piece p (= 4 token rows x 256 B) of every region; this wave owns pieces 2*wave, 2*wave+1.
-  // lane -> row 4p + lane/16, physical chunk lane%16, logical chunk = physical ^ ((row&3)<<2).
+  // A region is two sub-blocks of [64 token rows][64 columns] (128-B rows), one per column half.
+  // DMA: piece p = 8 token rows x 128 B of sub-block p/8 (the same request shape as gemm_nt's: one full
+  // line per row); this wave owns pieces 2*wave, 2*wave+1.  lane -> row 8*(p%8) + lane/8, physical
+  // chunk lane%8, logical chunk = physical ^ (((row>>1)&1)<<2): rows r, r+2 swap 64-B halves, which puts
+  // the four rows a transpose read touches in one LDS cycle on four disjoint bank quarters.
   int prow[2], acol[2][2], bcol[2][2];            // [piece][region half]
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    prow[j] = (wave * 2 + j) * 4 + (lane >> 4);
-    const int rc = ((lane & 15) ^ ((prow[j] & 3) << 2)) * 8;        // region column 0..127
+    const int pc = wave * 2 + j, sub = pc >> 3;
+    prow[j] = (pc & 7) * 8 + (lane >> 3);
+    const int rc = sub * 64 + ((lane & 7) ^ (((prow[j] >> 1) & 1) << 2)) * 8;   // region column 0..127
     acol[j][0] = r0 + (rc >> 6) * 128 + (rc & 63); acol[j][1] = acol[j][0] + 64;
-    bcol[j][0] = c0 + rc; bcol[j][1] = bcol[j][0] + 128;   // whole 128-B lines: wave wc owns columns wc*32+[0,32) of each half
+    bcol[j][0] = c0 + rc; bcol[j][1] = bcol[j][0] + 128;   // wave wc owns columns wc*32+[0,32) of each half
   }
   // Row maps without a division per DMA: phys(m) = base + m + (m / grp) * skip.  Every region kind is
   // requested for K tiles 0, 1, 2, ... in order, so keep (quotient, remainder) of its next tile's
@@ -619,27 +623,27 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
 
   // transposed fragment addressing inside a region: token row ks*16 + tr_row (+4), column c
   const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
-  const int tr_sw = ((lane & 15) >> 2) << 2;
+  const int tr_sw = ((lane >> 3) & 1) << 2;                  // ((row>>1)&1)<<2 for rows tr_row, tr_row+4 (+16 ks)
   const int cl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);   // column of this lane inside a 32-column group
   int fa_off[2], fb_off;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = wr * 64 + i * 32 + cl;
-    fa_off[i] = tr_row * 128 + (((c >> 3) ^ tr_sw) << 3) + (c & 7);
+    const int cc = i * 32 + cl;                              // column inside sub-block wr
+    fa_off[i] = wr * 4096 + tr_row * 64 + (((cc >> 3) ^ tr_sw) << 3) + (cc & 7);
   }
   {
-    const int c = wc * 32 + cl;
-    fb_off = tr_row * 128 + (((c >> 3) ^ tr_sw) << 3) + (c & 7);
+    const int cc = (wc & 1) * 32 + cl;                       // column inside sub-block wc>>1
+    fb_off = (wc >> 1) * 4096 + tr_row * 64 + (((cc >> 3) ^ tr_sw) << 3) + (cc & 7);
   }
-  // column sums: thread -> physical chunk tid&15 of rows tid>>4 and (tid>>4)+32
+  // column sums: thread -> sub-block tid>>8, physical chunk tid&7 of rows (tid>>3)&31 and +32
   const bool do_cs = out.cslab != nullptr && t2 == 0;
-  const int cs_row = tid >> 4, cs_pc = tid & 15;
+  const int cs_sub = tid >> 8, cs_row = (tid >> 3) & 31, cs_pc = tid & 7;
   float cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TP_COLSUM(buf_, kind_, cs_)                                                                      \
   if (do_cs) {                                                                                           \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                   \
       const uint4 v = *reinterpret_cast<const uint4*>(lds + (buf_) * TP_BUF + (kind_) * TP_REGION +      \
-                                                      (cs_row + 32 * it) * 128 + cs_pc * 8);             \
+                                                      cs_sub * 4096 + (cs_row + 32 * it) * 64 + cs_pc * 8); \
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};                                                        \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
         cs_[2 * j] += __uint_as_float(w[j] << 16);                                                       \
@@ -650,16 +654,16 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
 #define TP_TR(ptr_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr_))
 #define TP_READ_A(buf_, kind_)                                                                           \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {       \
-    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 128 + fa_off[i];         \
+    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 64 + fa_off[i];          \
     union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
-    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 128);                                                  \
+    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 64);                                                  \
     fa[i][ks] = u_.v;                                                                                    \
   }
 #define TP_READ_B(buf_, kind_, fb_)                                                                      \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
-    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 128 + fb_off;            \
+    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 64 + fb_off;             \
     union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
-    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 128);                                                  \
+    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 64);                                                  \
     fb_[ks] = u_.v;                                                                                      \
   }
 #define TP_MMA(i0_, j_, fb_, ISSUE_)                                                                     \
@@ -725,11 +729,10 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
 #undef TP_MMA
 #undef TP_BAR
   if (do_cs) {
-    // logical chunk of this thread = cs_pc ^ ((cs_row&3)<<2) (rows cs_row and cs_row+32 share row&3);
-    // region column rc -> tile column: A0: (rc>>6)*128 + (rc&63), A1: +64
+    // logical chunk of this thread = cs_pc ^ (((cs_row>>1)&1)<<2) (rows cs_row, cs_row+32 share bit 1);
+    // sub-block s of A0 = tile columns s*128 + [0,64), of A1 = s*128 + 64 + [0,64)
     float* red = reinterpret_cast<float*>(smem);            // [32][256] floats = 32 KB (ring is free)
-    const int rc = (cs_pc ^ ((cs_row & 3) << 2)) * 8;
-    const int tc = (rc >> 6) * 128 + (rc & 63);
+    const int tc = cs_sub * 128 + (cs_pc ^ (((cs_row >> 1) & 1) << 2)) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       red[cs_row * 256 + tc + j] = cs0[j];

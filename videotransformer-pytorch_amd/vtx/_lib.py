@@ -142,7 +142,17 @@ def check(rc, what=''):
         raise VtxError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
 
 
+_TRACE = os.environ.get('VTX_TRACE_CALLS', '0') == '1'
+
+
 def call(name, *args):
+    if _TRACE:                      # debugging aid: name every launch and wait for it (finds the faulting kernel)
+        import sys
+        import torch
+        sys.stderr.write(f'[vtx] {name}\n')
+        sys.stderr.flush()
     rc = getattr(load(), name)(*args)
     if rc != 0:
         check(rc, name)
+    if _TRACE:
+        torch.cuda.synchronize()

@@ -131,6 +131,9 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
     d.split_row = int(split_row); d.Csplit = ptr(Csplit); d.ldsplit = N
     b2 = _f32(bias2)
     d.bias2 = ptr(b2)
+    if _lib._TRACE:
+        import sys
+        sys.stderr.write(f'[vtx]   gemm_nt M={M} N={N} K={K} lda={d.lda} ldc={d.ldc} A={tuple(A.shape)} B={tuple(B.shape)} C={tuple(Cout.shape)} amap=({amap.grp},{amap.skip},{amap.base}) cmap=({cmap.grp},{cmap.skip},{cmap.base}) bias={bias is not None} rs={row_scale is not None} R={R is not None} split={split_row}\n')
     with _timed('gemm_nt', 2.0 * M * N * K):
         call('vtx_gemm_nt', C.byref(d), stream())
 
