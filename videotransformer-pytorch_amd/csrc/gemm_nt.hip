@@ -374,7 +374,7 @@ __device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory
 // under-wait on the DMA, because loads retire in order among themselves.)
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
-    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, EpiParams ep) {
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -383,11 +383,20 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   float* stg = reinterpret_cast<float*>(smem + PP_RING_BYTES) + wave * 16 * PP_STG_LD;
   const int nk = K / PP_BK;
 
-  // this workgroup's tiles: t = first + i * step, i = 0 .. count-1
+  // Tile walk.  XCD x owns the row tiles [rlo, rhi) for ALL column tiles and walks them column-group
+  // major: CG column tiles at a time over all its row tiles, so the 32 workgroups of an XCD work on
+  // 32/CG row tiles x CG column tiles at any moment: the CG weight panels (CG x 256 x K) are re-read by
+  // every row tile while they are hot in the XCD's 4 MB L2 / the Infinity Cache, and every activation
+  // line is shared by CG workgroups.
+  // (The loop is bound by the ~64 outstanding 128-B misses of a CU's vector L1 times the L2 latency --
+  // TCP_PENDING_STALL 40 % of the time, average TCP->TCC read latency 394 cycles at a 45 % L2 miss rate
+  // with the old row-major order of 2.7 row tiles x 12 column tiles -- so the L2 hit rate IS the speed.)
+  // Workgroup (xcd, slot) takes local tiles slot, slot + per, ...
   const int per = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int q = tiles_total >> 3, rem = tiles_total & 7;
-  const int xstart = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  const int xcount = xcd < rem ? q + 1 : q;
+  const int tiles_m = tiles_total / tiles_n;
+  const int rlo = (int)((long)tiles_m * xcd / 8), rhi = (int)((long)tiles_m * (xcd + 1) / 8);
+  const int nrow = rhi - rlo;
+  const int xcount = nrow * tiles_n;
   if (slot >= xcount) return;
   // De-synchronise the CUs.  Every tile takes the same time, so all 256 workgroups would reach their
   // epilogues together and share HBM's write bandwidth for the 128-KB C tiles (measured: the stores
@@ -404,8 +413,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 
   const bf16raw* src[4][2];                      // region kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
   int m0 = 0, n0 = 0;
-  auto set_tile = [&](int t) {
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  auto set_tile = [&](int t) {                  // t = local tile index of this XCD
+    const int grp_tiles = nrow * CG;             // tiles in a full column group
+    const int g = t / grp_tiles;
+    const int wg = min(CG, tiles_n - g * CG);    // width of this group (the last one may be narrower)
+    const int r = t - g * grp_tiles;
+    const int rr = r / wg, cc = r - rr * wg;
+    const int tm = rlo + rr, tn = g * CG + cc;
     m0 = tm * PP_BM; n0 = tn * PP_BN;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                // this wave owns pieces 2*wave, 2*wave+1 (8 region rows each)
@@ -459,8 +473,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #define PP_BAR() __builtin_amdgcn_s_barrier()
 
   const int step = per;
-  int t = xstart + slot;
-  const int tend = xstart + xcount;
+  int t = slot;
+  const int tend = xcount;
   set_tile(t);
   prologue();
   while (true) {
@@ -548,10 +562,17 @@ static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st
   // estimated time of one tile in 10-ns ticks of the constant 100 MHz clock (1.5 us per K tile + 6 us)
   const char* sk = getenv("VTX_GEMM_PP_SKEW");
   const int tile_ticks = (int)((sk ? atof(sk) : 1.0) * (150 * (d->K / PP_BK) + 600));
+  // column tiles per group (tools/gemm_cg.py, M = 100352: 1 is 15 % slower at N = 3072, 3..8 are within noise;
+  // K = 3072 wants >= 3): about 6 MB of weight panels, between 3 and 6 tiles
+  const char* cge = getenv("VTX_GEMM_PP_CG");
+  int cg = cge ? atoi(cge) : (int)(6291456L / (512L * d->K));
+  if (!cge && cg < 3) cg = 3;
+  if (!cge && cg > 6) cg = 6;
+  if (cg < 1) cg = 1;
   const char* gs = getenv("VTX_GEMM_PP_GRID");
   const int grid = gs ? atoi(gs) : PP_GRID;
   hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel, dim3(grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
-                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, ep);
+                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg, ep);
   return check_launch("gemm_nt_pp");
 }
 
