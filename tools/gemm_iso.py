@@ -10,8 +10,7 @@ os.environ['VTX_GEMM_PP_SKEW'] = '0'
 N, K = 3072, 768
 for grid, M in ((8, 2048), (64, 2048 * 8), (256, 2048 * 32)):
     os.environ['VTX_GEMM_PP_GRID'] = str(grid)
-    for dbg in (0, 1, 4):
-        os.environ['VTX_GEMM_DBG'] = str(dbg)
+    for dbg in (0,):
         a = torch.randn(M, K, device='cuda').bfloat16()
         w = torch.randn(N, K, device='cuda').bfloat16()
         c = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
