@@ -42,6 +42,18 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
   const int wave = threadIdx.x >> 6;
   const long total_waves = (long)gridDim.x * LN_WAVES;
   const float invD = 1.0f / (float)D;
+  // gamma / beta of this lane's columns stay in registers across the row loop (re-reading them per row
+  // is 4x the L1 traffic of the bf16 row itself)
+  float gm[NCH][4], bt[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = 4 * (lane + 64 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[c][j] = (col < D) ? gamma[col + j] : 0.f;
+      bt[c][j] = (col < D) ? beta[col + j] : 0.f;
+    }
+  }
   for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += total_waves) {
     const T* xr = x + map_row(xmap, r) * ldx;
     float v[NCH][4];
@@ -72,13 +84,9 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
       if (col < D) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + col);
-        const float4 b = *reinterpret_cast<const float4*>(beta + col);
         float o[4];
-        o[0] = (v[c][0] - mu) * rstd * g.x + b.x;
-        o[1] = (v[c][1] - mu) * rstd * g.y + b.y;
-        o[2] = (v[c][2] - mu) * rstd * g.z + b.z;
-        o[3] = (v[c][3] - mu) * rstd * g.w + b.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rstd * gm[c][j] + bt[c][j];
         st4<T>(yr + col, o);
       }
     }
@@ -218,7 +226,7 @@ int launch_reduce_partials(const float* part, int nslabs, long stride, long N, f
 
 static int ln_blocks(int rows) {
   int b = cdiv(rows, LN_WAVES);
-  return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+  return b > 2048 ? 2048 : (b < 1 ? 1 : b);    // 8 waves per SIMD: the kernel is bound by bytes in flight
 }
 // backward keeps per-block partial sums of dgamma/dbeta: fewer, fatter blocks
 static int ln_bwd_blocks(int rows) {
