@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, 'videotransformer-pytorch_amd'), os.path.join
 import torch
 from vtx import ops
 from kernel_bench import timeit
-M = 50176
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 50176
 for N in (768, 3072):
     for K in (128, 256, 512, 768, 1536, 3072):
         a = torch.randn(M, K, device='cuda').bfloat16()
@@ -15,7 +15,7 @@ for N in (768, 3072):
         t = timeit(lambda: ops.gemm_nt(a, w, c, M, N, K))
         print(f'NT M={M} N={N} K={K}: {t*1e6:8.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF', flush=True)
 for (K1, K2) in ((768, 768), (768, 3072), (3072, 768), (2304, 768)):
-    for M2 in (12544, 25088, 50176):
+    for M2 in ((M // 4, M // 2, M) if len(sys.argv) < 3 else (M,)):
         x = torch.randn(M2, K1, device='cuda').bfloat16()
         y = torch.randn(M2, K2, device='cuda').bfloat16()
         t = timeit(lambda: ops.gemm_tn(x, y, M2, K1, K2))

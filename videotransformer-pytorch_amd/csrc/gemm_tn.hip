@@ -971,8 +971,12 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     const bool safe = safe_env && atoi(safe_env) != 0;
     const char* nodma = getenv("VTX_GEMM_NODMA");
     const char* tnv = getenv("VTX_GEMM_TN");            // tuning override: pp256 | ring | dma2
-    const bool want_ring = !(tnv && std::string(tnv) == "dma2") && d->M >= 1024;
-    const bool want_pp = !(tnv && std::string(tnv) != "pp256") && tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
+    const bool want_ring = !(tnv && std::string(tnv) == "dma2") && d->M >= 1024;   // "pp256" falls back to the ring when ineligible
+    // Default is the 256x128 ring (2 workgroups per CU): with the XCD-aware split-major order it is as fast
+    // or faster than the 256x256 ping-pong kernel on every weight-gradient shape of the model
+    // (tools/gemm_sweep.py 100352: 2304x768 475 vs 513 us, 768x3072 648 vs 666 us, 768x768 202 vs 195 us);
+    // both are bound by the CU's L1 miss capacity.  VTX_GEMM_TN=pp256 selects the ping-pong kernel.
+    const bool want_pp = tnv && std::string(tnv) == "pp256" && tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
     if (!safe && !(nodma && atoi(nodma) != 0) && want_pp) {
       const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
       const int s_p = tp_splits(d->M, d->N1, d->N2);
@@ -995,8 +999,13 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     }
     if (!safe && !(nodma && atoi(nodma) != 0) && want_ring) {
       const int tiles1r = cdiv(d->N1, 256);
-      int s_r = cdiv(512, tiles1r * tiles2);
-      if (s_r > splits) s_r = splits;
+      // one resident round: 2 workgroups per CU x 256 CUs = 512 slots, as full as the workspace allows
+      int s_r = 512 / (tiles1r * tiles2);
+      const int ws_splits = (tp_eligible(d->M, d->N1, d->N2) && tp_splits(d->M, d->N1, d->N2) > splits)
+                                ? tp_splits(d->M, d->N1, d->N2) : splits;   // slabs vtx_gemm_tn_workspace sized
+      if (s_r > ws_splits) s_r = ws_splits;
+      if (s_r > d->M / (2 * TR_BKM)) s_r = d->M / (2 * TR_BKM);
+      if (s_r < 1) s_r = 1;
       int m_per_r = cdiv(cdiv(d->M, s_r), TR_BKM) * TR_BKM;
       const size_t ring_bytes = (size_t)TR_NBUF * TR_STAGE * 2;
       const size_t lds_r = ring_bytes > (size_t)8 * 32 * STAGE_LD * 4 ? ring_bytes : (size_t)8 * 32 * STAGE_LD * 4;
