@@ -135,9 +135,11 @@ def main():
     torch.set_num_threads(max(1, min(_host_cores() // max(world, 1), 16)))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    force_dp = os.environ.get('VTX_FORCE_DP', '0') == '1'     # 1-rank RCCL group: exercises the DP path on one GPU
+    if world > 1 or force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
     import __graft_entry__ as ge
     ge.ensure_built()
     import vtx
@@ -157,7 +159,7 @@ def main():
     params = list(model.parameters()) + list(head.parameters())
     dp.broadcast_parameters(model)
     dp.broadcast_parameters(head)
-    buckets = dp.GradBuckets(params) if world > 1 else None
+    buckets = dp.GradBuckets(params, force_comm=force_dp) if (world > 1 or force_dp) else None
     opt = None if args.no_optimizer else torch.optim.SGD(params, lr=1e-4, momentum=0.9, nesterov=True)
 
     B = args.batch
@@ -248,9 +250,20 @@ def main():
             out['breakdown'] = breakdown
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_subprocess(args.frames)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    else:
+        out = None
+    # tear the process group down first and flush C stdio (RCCL prints its version banner through it), so
+    # that the JSON line is the LAST thing this job writes to stdout
+    if world > 1 or force_dp:
+        dist.barrier()
         dist.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

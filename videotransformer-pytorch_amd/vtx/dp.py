@@ -20,8 +20,9 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, comm_dtype=None):
+    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, comm_dtype=None, force_comm=False):
         self.group = process_group
+        self.force_comm = force_comm            # issue the collectives even in a 1-rank group (exercises RCCL)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype            # e.g. torch.bfloat16 to halve xGMI bytes (lossy)
         params = [p for p in params if p.requires_grad]
@@ -61,7 +62,7 @@ class GradBuckets:
         return hook
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 and not self.force_comm:
             return
         buf = b['flat']
         if self.comm_dtype is not None and self.comm_dtype != buf.dtype:
