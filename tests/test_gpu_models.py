@@ -117,6 +117,21 @@ def test_timesformer_b_t8_train_vs_golden(prec, tol, gtol):
     check(f'TimeSformer-B T=8 {prec} attention', att[:2, :, :8, :8].cpu(), ge['attn_head'], tol)
 
 
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+def test_timesformer_b_t16_train_vs_golden(prec, tol, gtol):
+    """The north_star's second clip shape: TimeSformer-B on 16x3x224x224, train mode with DropPath,
+    fwd+bwd against the reference's own run (tests/golden/make_golden_t16.py).  Temporal attention
+    here packs two 16-token sequences per 32-row MFMA tile."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold('tsf_b_t16_train.npz')
+    m, _ = _build(V.TimeSformer, 0, num_frames=16)
+    y, grads = _train_step(m, synth.synth_clip(1, 16, seed=21), 9, 768)
+    check(f'TimeSformer-B T=16 train {prec} out', y.cpu(), g['out'], tol)
+    compare_grads(f'TimeSformer-B T=16 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
+
+
 @pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
 def test_vivit_b_forward(prec, tol):
     """BASELINE.json configs[2] shape: ViViT-B fact_encoder, Conv3d tubelets, 16 frames."""
