@@ -93,6 +93,15 @@ def test_gemm_nt_bf16_variants(variant, monkeypatch):
         C = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
         ops.gemm_nt(dev(A, torch.bfloat16), dev(W, torch.bfloat16), C, M, N, K, bias=dev(b))
         check(f'gemm_nt {variant} {M}x{N}x{K}', C.float().cpu(), ref, 1e-2)
+        if variant == 'pp256':
+            # the persistent kernel draws tiles from per-XCD counters: any grid (= any number of resident
+            # workgroups) must produce the same result, and the counters must be left clean for the next launch
+            for grid in ('40', '8', '256'):
+                monkeypatch.setenv('VTX_GEMM_PP_GRID', grid)
+                C2 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+                ops.gemm_nt(dev(A, torch.bfloat16), dev(W, torch.bfloat16), C2, M, N, K, bias=dev(b))
+                assert torch.equal(C2, C), f'pp256 grid {grid}: result depends on the grid size'
+            monkeypatch.delenv('VTX_GEMM_PP_GRID')
 
 
 @pytest.mark.parametrize('nodma', ['0', '1'])

@@ -374,7 +374,8 @@ __device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory
 // under-wait on the DMA, because loads retire in order among themselves.)
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
-    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, EpiParams ep) {
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, int* __restrict__ tile_ctr,
+    EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -391,21 +392,48 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   // (The loop is bound by the ~64 outstanding 128-B misses of a CU's vector L1 times the L2 latency --
   // TCP_PENDING_STALL 40 % of the time, average TCP->TCC read latency 394 cycles at a 45 % L2 miss rate
   // with the old row-major order of 2.7 row tiles x 12 column tiles -- so the L2 hit rate IS the speed.)
-  // Workgroup (xcd, slot) takes local tiles slot, slot + per, ...
+  // The workgroups of an XCD draw local tile indices from the XCD's counter (one atomicAdd per tile,
+  // broadcast through an LDS word): a static slot -> tile assignment doubles the kernel time as soon as
+  // fewer than 256 workgroups are resident, e.g. while an RCCL collective of the data-parallel gradient
+  // exchange holds a few CUs.
   const int per = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tiles_m = tiles_total / tiles_n;
   const int rlo = (int)((long)tiles_m * xcd / 8), rhi = (int)((long)tiles_m * (xcd + 1) / 8);
   const int nrow = rhi - rlo;
   const int xcount = nrow * tiles_n;
-  if (slot >= xcount) return;
+  int* const my_ctr = tile_ctr + xcd * 16;       // one 64-B line per XCD
+  // The counters clean up after themselves: every workgroup checks out through `done` when it leaves, and
+  // the last one of the grid zeroes the set for the next launch (stream order makes that visible).
+  auto check_out = [&]() {
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(tile_ctr + 8 * 16, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) tile_ctr[x * 16] = 0;
+        __threadfence();
+      }
+    }
+  };
+  if (xcount == 0) { check_out(); return; }
+  volatile int* const bcast = reinterpret_cast<volatile int*>(smem + PP_RING_BYTES);   // staging is idle between epilogues
+  auto next_tile = [&]() -> int {                // every wave is between tiles (no LDS traffic, groups aligned)
+    if (tid == 0) *bcast = atomicAdd(my_ctr, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int t = *bcast;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // the word may be overwritten (epilogue staging) only after all have read it
+    return __builtin_amdgcn_readfirstlane(t);
+  };
   // De-synchronise the CUs.  Every tile takes the same time, so all 256 workgroups would reach their
   // epilogues together and share HBM's write bandwidth for the 128-KB C tiles (measured: the stores
-  // then cost their full HBM time, ~10 us per tile, un-overlapped).  Workgroups that own one tile
-  // fewer than the busiest ones have a tile's worth of slack: spend it up front, spread uniformly.
+  // then cost their full HBM time, ~10 us per tile, un-overlapped).  The last round of tiles is
+  // partial (frac = xcount/per - floor): spread the start times over that slack, uniformly by slot.
   {
-    const int nfull = xcount % per;              // slots [0, nfull) own ceil(xcount/per) tiles
-    if (nfull != 0 && slot >= nfull && tile_ticks > 0) {
-      const long wait = (long)tile_ticks * (2 * (slot - nfull) + 1) / (2 * (per - nfull));
+    const int nfull = xcount % per;              // tiles of the partial round (0: no slack, use half a tile)
+    const long slack = nfull ? (long)tile_ticks * (per - nfull) / per : tile_ticks / 2;
+    if (tile_ticks > 0 && per > 1) {
+      const long wait = slack * slot / per;
       const long t0 = __builtin_amdgcn_s_memrealtime();
       while ((long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
@@ -472,9 +500,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   __builtin_amdgcn_s_setprio(0);
 #define PP_BAR() __builtin_amdgcn_s_barrier()
 
-  const int step = per;
-  int t = slot;
+  int t = next_tile();
   const int tend = xcount;
+  if (t >= tend) { check_out(); return; }
   set_tile(t);
   prologue();
   while (true) {
@@ -525,7 +553,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
     const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
-    t += step;
+    t = next_tile();
     const bool more = t < tend;
     if (more) { set_tile(t); prologue(); }        // ring is free: request the next tile before the epilogue
     // eight 16-row passes, expanded by hand: a loop here makes the compiler index acc[] dynamically
@@ -545,6 +573,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #undef PP_EPI
     if (!more) break;
   }
+  check_out();
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_MMA
@@ -571,8 +600,19 @@ static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st
   if (cg < 1) cg = 1;
   const char* gs = getenv("VTX_GEMM_PP_GRID");
   const int grid = gs ? atoi(gs) : PP_GRID;
+  // per-XCD tile counters + a check-out counter (9 x 64 B), allocated and zeroed on first use; the kernel
+  // leaves them zeroed.  One set per process: ping-pong GEMMs must not run concurrently on two streams.
+  static int* ctr = nullptr;
+  if (!ctr) {
+    if (hipMalloc(reinterpret_cast<void**>(&ctr), 9 * 64) != hipSuccess || hipMemset(ctr, 0, 9 * 64) != hipSuccess) {
+      ctr = nullptr;
+      set_error("gemm_nt_pp: cannot allocate the tile counters");
+      return VTX_EINVAL;
+    }
+  }
   hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel, dim3(grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
-                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg, ep);
+                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg,
+                     ctr, ep);
   return check_launch("gemm_nt_pp");
 }
 
