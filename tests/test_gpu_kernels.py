@@ -179,7 +179,7 @@ def test_gemm_nt_epilogues(dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304), (12552, 768, 768),
-                                     (1031, 216, 768), (4099, 3072, 768), (1024, 8, 136)])
+                                     (1031, 216, 768), (4099, 3072, 768), (1024, 8, 136), (4131, 1024, 1280)])
 def test_gemm_tn(dtype, M, N1, N2, monkeypatch):
     from vtx import ops
     A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
