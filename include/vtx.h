@@ -9,8 +9,12 @@
  * Conventions (all entry points):
  *   - extern "C", plain pointers and sizes, no torch types.
  *   - every device pointer is BORROWED for the call; the library never
- *     allocates, frees or synchronises; work is enqueued on `stream`
- *     (a hipStream_t passed as void*; NULL = the null stream).
+ *     frees or synchronises, and never allocates except for ONE 576-byte
+ *     tile-counter buffer per process that the large bf16 vtx_gemm_nt keeps
+ *     (allocated on its first call; its persistent kernel hands out tiles
+ *     through it, so such calls must not overlap on two streams); work is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream).
  *   - returns VTX_OK (0) or a negative VTX_E* code; never throws.
  *     vtx_last_error_string() gives the reason for the last failure on the
  *     calling thread.
