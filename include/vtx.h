@@ -193,6 +193,15 @@ int vtx_cast_to_f32(int dtype, size_t n, const void* src, float* dst, void* stre
  * fact_encoder, space_only). */
 int vtx_patch_rows(int dtype, int B, int T, int C, int H, int W, int ps, int ts,
                    const float* clip, void* rows, long ldr, int frame_major, void* stream);
+/* Same rows straight from decoded video: clip [B,T,H,W,3] uint8, channels last (what
+ * dataset.py:171 holds before its permute), with the reference's ToTensor
+ * (x.float().div(255), data_transform.py:52-63) and transforms.Normalize
+ * ((x - mean[c]) / std[c], data_transform.py:534-539) applied on the fly in that
+ * order (fp32 rows bit-identical to vtx_patch_rows of the normalised clip).
+ * mean3 / std3 are HOST pointers to 3 floats. */
+int vtx_patch_rows_u8(int dtype, int B, int T, int H, int W, int ps, int ts,
+                      const unsigned char* clip, const float* host_mean3, const float* host_std3,
+                      void* rows, long ldr, int frame_major, void* stream);
 /* E[p*T+t,:] = bias + pos[1+p,:] + (time ? time[t,:] : 0);  cls_row = cls + pos[0]
  * (prepare_tokens, video_transformer.py:199-237).  E, cls_row in `dtype`. */
 int vtx_embed_table(int dtype, int P, int T, int D, const float* bias, const float* pos,

@@ -383,6 +383,42 @@ def test_patch_rows_bit_exact(ts):
     report(f'ok   patch_rows bit-exact ts={ts}')
 
 
+@pytest.mark.parametrize('ts', [1, 2])
+def test_patch_rows_uint8_ingest_bit_exact(ts):
+    """uint8 [B,T,H,W,3] clip -> normalised patch rows in one pass: bit-identical (fp32) to the reference's
+    own order of operations -- permute to [T,C,H,W] (dataset.py:171), ToTensor = x.float().div(255)
+    (data_transform.py:52-63), transforms.Normalize = sub(mean).div(std) (:534-539) -- followed by the
+    fp32 patch gather; every uint8 value occurs."""
+    from oracle import vt_oracle as O
+    import vtx
+    from vtx import ops
+    B, T, H, W, ps = 2, 4, 64, 48, 16
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    u8[0, 0, 0, :, 0] = torch.arange(48, dtype=torch.uint8) * 5
+    u8[0, 0, 1].view(-1)[:144] = torch.arange(144, dtype=torch.uint8)
+    u8[0, 0, 2].view(-1)[:112] = torch.arange(144, 256, dtype=torch.uint8)
+    mean, std = [0.45, 0.456, 0.406], [0.225, 0.224, 0.229]
+    x = u8.permute(0, 1, 4, 2, 3).float().div(255)                                  # ToTensor
+    x = x.sub(torch.tensor(mean).view(1, 1, 3, 1, 1)).div(torch.tensor(std).view(1, 1, 3, 1, 1))   # Normalize
+    want = (O.patch_rows_2d(x, ps) if ts == 1 else O.patch_rows_3d(x, ps, ts))
+    Tq, P = T // ts, (H // ps) * (W // ps)
+    vtx.set_input_normalization(mean, std)
+    try:
+        got = ops.patch_rows(u8.to(DEV), torch.float32, ps, ts, frame_major=True).cpu()
+        assert torch.equal(got, want.reshape(B * Tq * P, -1)), 'uint8 ingest: frame-major rows differ'
+        got = ops.patch_rows(u8.to(DEV), torch.float32, ps, ts, frame_major=False).cpu()
+        want_pt = want.reshape(B, Tq, P, -1).permute(0, 2, 1, 3).reshape(B * P * Tq, -1)
+        assert torch.equal(got, want_pt), 'uint8 ingest: token-order rows differ'
+        got16 = ops.patch_rows(u8.to(DEV), torch.bfloat16, ps, ts, frame_major=False).cpu()
+        assert torch.equal(got16, want_pt.to(torch.bfloat16)), 'uint8 ingest: bf16 rows differ from the rounded fp32 rows'
+    finally:
+        vtx.set_input_normalization(None, None)
+    with pytest.raises(ValueError):
+        ops.patch_rows(u8.to(DEV), torch.float32, ps, ts, frame_major=True)           # no normalisation set
+    report(f'ok   patch_rows uint8 ingest bit-exact ts={ts}')
+
+
 # ---------------------------------------------------------------------------------- HOG
 def _hog_frames():
     fr = [np.random.RandomState(s).randint(0, 256, (224, 224, 3)).astype(np.uint8) for s in (1234, 7)]

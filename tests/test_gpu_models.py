@@ -184,6 +184,31 @@ def test_fused_proj_tfc_matches_unfused(monkeypatch):
             check(f'fused proj.tfc grad {n}', outs[1][1][n], outs[0][1][n], 1e-3)
 
 
+def test_uint8_clip_input_equals_float_input():
+    """A decoded uint8 [B,T,H,W,3] clip fed to the model (vtx.set_input_normalization) gives exactly the
+    output of the reference-style float [B,T,C,H,W] input produced by ToTensor + Normalize."""
+    import vtx
+    import video_transformer as V
+    mean, std = [0.45, 0.45, 0.45], [0.225, 0.225, 0.225]
+    g = torch.Generator().manual_seed(8)
+    u8 = torch.randint(0, 256, (2, 4, 64, 64, 3), generator=g, dtype=torch.uint8)
+    xf = u8.permute(0, 1, 4, 2, 3).float().div(255)
+    xf = xf.sub(torch.tensor(mean).view(1, 1, 3, 1, 1)).div(torch.tensor(std).view(1, 1, 3, 1, 1))
+    for cls, kw in ((V.TimeSformer, dict(num_frames=4)), (V.ViViT, dict(num_frames=4))):
+        for prec in ('fp32', 'bf16'):
+            vtx.set_precision(prec)
+            m, _ = _build(cls, 5, **kw, **SMALL)
+            m.eval()
+            vtx.set_input_normalization(mean, std)
+            try:
+                with torch.no_grad():
+                    y8 = m(u8.to(DEV))
+                    yf = m(xf.to(DEV))
+            finally:
+                vtx.set_input_normalization(None, None)
+            assert torch.equal(y8, yf), f'{cls.__name__} {prec}: uint8 and float inputs disagree'
+
+
 def test_autocast_selects_bf16_path():
     import vtx
     import video_transformer as V

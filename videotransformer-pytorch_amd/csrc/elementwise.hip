@@ -195,6 +195,49 @@ __global__ void patch_rows_kernel(int B, int Tn, int C, int H, int W, int ps, in
   }
 }
 
+// ---- patch gather straight from decoded video: clip [B,T,H,W,3] uint8 (channels last) --------------
+// Fuses the reference's ToTensor (x.float().div(255), data_transform.py:52-63) and
+// transforms.Normalize ((x - mean[c]) / std[c], data_transform.py:534-539) into the gather: the three
+// IEEE operations in the reference's order, so the fp32 rows are bit-identical to patch_rows() of the
+// normalised fp32 clip, and the clip crosses HBM once as 1 byte per sample instead of 4 + 4 + 4.
+// One thread per (row, kt, kh): reads ps pixels x 3 channels = 3*ps contiguous bytes (48 B at ps = 16).
+template <typename T>
+__global__ void patch_rows_u8_kernel(int B, int Tn, int H, int W, int ps, int ts, const uint8_t* __restrict__ clip,
+                                     float m0, float m1, float m2, float s0, float s1, float s2,
+                                     T* __restrict__ rows, long ldr, int frame_major) {
+#pragma clang fp contract(off)
+  const int gh = H / ps, gw = W / ps, P = gh * gw, Tq = Tn / ts;
+  const long total = (long)B * Tq * P * ts * ps;
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;                                   // idx -> (b, tq, ph, kt, kh, pw): pw fastest
+    const int pw = (int)(r % gw); r /= gw;
+    const int kh = (int)(r % ps); r /= ps;
+    const int kt = (int)(r % ts); r /= ts;
+    const int ph = (int)(r % gh); r /= gh;
+    const int tq = (int)(r % Tq); r /= Tq;
+    const int b = (int)r;
+    const uint8_t* src = clip + ((((long)b * Tn + (tq * ts + kt)) * H + (ph * ps + kh)) * W + pw * ps) * 3;
+    const int p = ph * gw + pw;
+    const long row = frame_major ? ((long)b * Tq + tq) * P + p : ((long)b * P + p) * Tq + tq;
+    T* dst = rows + row * ldr + ((long)kt * ps + kh) * ps;
+    for (int kw = 0; kw < ps; kw += 4) {            // 12 bytes = 4 pixels x 3 channels
+      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(src + kw * 3);
+      const uint32_t w1 = *reinterpret_cast<const uint32_t*>(src + kw * 3 + 4);
+      const uint32_t w2 = *reinterpret_cast<const uint32_t*>(src + kw * 3 + 8);
+      const uint32_t by[12] = {w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255, w0 >> 24, w1 & 255, (w1 >> 8) & 255,
+                               (w1 >> 16) & 255, w1 >> 24, w2 & 255, (w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = (float)by[3 * j + c] / 255.0f;
+          ET<T>::st(dst + (long)c * ts * ps * ps + kw + j, (x - mean[c]) / sd[c]);
+        }
+    }
+  }
+}
+
 // ---- E[(p,t) or (t,p)] = bias + pos[1+p] + time[t];  cls_row = cls + pos[0] -------------
 template <typename T>
 __global__ void embed_table_kernel(int P, int Tn, int D, const float* __restrict__ bias, const float* __restrict__ pos,
@@ -339,6 +382,23 @@ extern "C" int vtx_patch_rows(int dtype, int B, int T, int C, int H, int W, int 
              hipLaunchKernelGGL(patch_rows_kernel<bf16raw>, grid, block, 0, st, B, T, C, H, W, ps, ts, clip, (bf16raw*)rows, ldr, frame_major),
              "patch_rows");
   return check_launch("patch_rows");
+}
+
+extern "C" int vtx_patch_rows_u8(int dtype, int B, int T, int H, int W, int ps, int ts, const unsigned char* clip,
+                                 const float* mean3, const float* std3, void* rows, long ldr, int frame_major, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && ps > 0 && ts > 0 && clip && rows && mean3 && std3, VTX_EINVAL, "patch_rows_u8: bad arguments");
+  VTX_REQUIRE(H % ps == 0 && W % ps == 0 && T % ts == 0 && ps % 4 == 0, VTX_EINVAL,
+              "patch_rows_u8: H,W must be multiples of ps (itself a multiple of 4), T of ts");
+  VTX_REQUIRE((reinterpret_cast<uintptr_t>(clip) & 3u) == 0, VTX_EALIGN, "patch_rows_u8: clip must be 4-byte aligned");
+  VTX_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, VTX_EINVAL, "patch_rows_u8: zero std");
+  const long work = (long)B * (T / ts) * (H / ps) * (W / ps) * ts * ps;
+  dim3 grid(grid_for(work, 256, 16384)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(patch_rows_u8_kernel<float>, grid, block, 0, st, B, T, H, W, ps, ts, clip, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)rows, ldr, frame_major),
+             hipLaunchKernelGGL(patch_rows_u8_kernel<bf16raw>, grid, block, 0, st, B, T, H, W, ps, ts, clip, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16raw*)rows, ldr, frame_major),
+             "patch_rows_u8");
+  return check_launch("patch_rows_u8");
 }
 
 extern "C" int vtx_embed_table(int dtype, int P, int T, int D, const float* bias, const float* pos, const float* time_embed,

@@ -133,7 +133,9 @@ class TimeSformer(_VideoTransformerBase):
                                   'is not implemented on the HIP path')
 
     def prepare_tokens(self, x):
-        b, t, c, h, w = x.shape
+        # x: float [B,T,C,H,W] (the reference's input) or, beyond the reference, the decoded uint8 clip
+        # [B,T,H,W,3] with vtx.set_input_normalization(mean, std) (ToTensor + Normalize fused into the gather)
+        b, t, c, h, w = vtx.ops.clip_dims(x)
         grid = (h // self.patch_embed.patch_size[0]) * (w // self.patch_embed.patch_size[1])
         if grid != self.pos_embed.shape[1] - 1 or w != h:
             raise NotImplementedError('vtx: input resolution must match img_size (no pos-embed interpolation)')

@@ -10,6 +10,7 @@ import torch
 
 from . import _lib, ops, functions  # noqa: F401
 from ._lib import VtxError, load  # noqa: F401
+from .ops import set_input_normalization  # noqa: F401
 
 _precision = 'auto'
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     'vtx_cast_from_f32': (ci, [ci, sz, vp, vp, vp]),
     'vtx_cast_to_f32': (ci, [ci, sz, vp, vp, vp]),
     'vtx_patch_rows': (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, cl, ci, vp]),
+    'vtx_patch_rows_u8': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, cl, ci, vp]),
     'vtx_embed_table': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     'vtx_hog_table_bytes': (sz, []),
     'vtx_hog_build_table': (ci, [vp]),

@@ -460,7 +460,7 @@ class TokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clip, conv_w, conv_b, cls_token, pos_embed, time_embed, dtype, layout):
         ops.need_cuda(clip, conv_w)
-        B, T, Cc, H, W = clip.shape
+        B, T, Cc, H, W = ops.clip_dims(clip)
         D = conv_w.shape[0]
         ps = conv_w.shape[-1]
         ts = conv_w.shape[2] if conv_w.ndim == 5 else 1
@@ -524,7 +524,7 @@ class PatchEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clip, conv_w, conv_b, dtype):
         ops.need_cuda(clip, conv_w)
-        B, T, Cc, H, W = clip.shape
+        B, T, Cc, H, W = ops.clip_dims(clip)
         D = conv_w.shape[0]
         ps = conv_w.shape[-1]
         ts = conv_w.shape[2] if conv_w.ndim == 5 else 1

@@ -295,9 +295,49 @@ def upload_f32(values_cpu, device):
     return out
 
 
+_input_norm = None          # (mean[3], std[3]) applied to uint8 clips (set_input_normalization)
+
+
+def set_input_normalization(mean, std):
+    """Mean / std of the reference's transforms.Normalize for uint8 [B,T,H,W,3] clips (the values the
+    reference is configured with, e.g. model_pretrain.py's --mean/--std); None disables uint8 input."""
+    global _input_norm
+    if mean is None:
+        _input_norm = None
+        return
+    mean, std = [float(v) for v in mean], [float(v) for v in std]
+    if len(mean) != 3 or len(std) != 3 or any(v == 0.0 for v in std):
+        raise ValueError('set_input_normalization: need 3 means and 3 non-zero stds')
+    _input_norm = (mean, std)
+
+
+def clip_dims(clip):
+    """(B, T, C, H, W) of a float [B,T,C,H,W] or a uint8 channels-last [B,T,H,W,3] clip."""
+    if clip.dtype == torch.uint8:
+        B, T, H, W, Cc = clip.shape
+        if Cc != 3:
+            raise ValueError('uint8 clips must be [B,T,H,W,3]')
+        return B, T, Cc, H, W
+    B, T, Cc, H, W = clip.shape
+    return B, T, Cc, H, W
+
+
 def patch_rows(clip, dtype, ps, ts, frame_major):
-    """[B,T,C,H,W] fp32 -> [B*(T/ts)*P, C*ts*ps*ps] rows in `dtype`."""
+    """[B,T,C,H,W] fp32 -> [B*(T/ts)*P, C*ts*ps*ps] rows in `dtype`; a uint8 [B,T,H,W,3] clip is
+    normalised on the fly (ToTensor + Normalize of the reference, see set_input_normalization)."""
     need_cuda(clip)
+    if clip.dtype == torch.uint8:
+        if _input_norm is None:
+            raise ValueError('uint8 clip: call vtx.set_input_normalization(mean, std) first')
+        clip = clip.contiguous()
+        B, T, Cc, H, W = clip_dims(clip)
+        K = Cc * ts * ps * ps
+        rows = torch.empty(B * (T // ts) * (H // ps) * (W // ps), K, dtype=dtype, device=clip.device)
+        mean = (C.c_float * 3)(*_input_norm[0])
+        std = (C.c_float * 3)(*_input_norm[1])
+        call('vtx_patch_rows_u8', _DT[dtype], B, T, H, W, ps, ts, ptr(clip), mean, std, ptr(rows), K, int(frame_major),
+             stream())
+        return rows
     if clip.dtype != torch.float32:
         clip = clip.float()
     clip = clip.contiguous()
