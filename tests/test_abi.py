@@ -54,3 +54,32 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     a = _lib.AttnDesc()
     a.S, a.L, a.H, a.hd = 1, 8, 2, 48                            # unsupported head dim
     assert lib.vtx_attn_fwd(ctypes.byref(a), None) == -1
+
+
+def test_struct_layouts_match_ctypes(tmp_path):
+    """The descriptor structs cross the boundary by pointer: the ctypes mirrors in vtx/_lib.py must have
+    the size and field offsets the C compiler gives include/vtx.h (compiled here as plain C)."""
+    import subprocess
+    from vtx import _lib
+    structs = {'vtx_rowmap': _lib.RowMap, 'vtx_gemm_desc': _lib.GemmDesc, 'vtx_gemm_tn_desc': _lib.GemmTnDesc,
+               'vtx_attn_desc': _lib.AttnDesc, 'vtx_attn_bwd_desc': _lib.AttnBwdDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "vtx.h")}"',
+             'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-o', str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {}
+    for ln in out.splitlines():
+        s, f, v = ln.split()
+        got[(s, f)] = int(v)
+    for cname, cls in structs.items():
+        assert got[(cname, 'size')] == ctypes.sizeof(cls), f'{cname}: sizeof differs'
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, f'{cname}.{fname}: offset differs'
