@@ -83,3 +83,22 @@ def test_struct_layouts_match_ctypes(tmp_path):
         assert got[(cname, 'size')] == ctypes.sizeof(cls), f'{cname}: sizeof differs'
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, f'{cname}.{fname}: offset differs'
+
+
+def test_bench_traffic_helper_reads_committed_pmc_passes():
+    """bench.py derives roofline.traffic from the committed rocprofv3 PMC dumps of the default command."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+
+    class A:
+        precision, frames = 'bf16', 8
+    t = mod.pmc_traffic_per_launch(64, A)
+    assert t is not None and 2e8 < t < 5e9, t            # a few hundred MB .. a few GB per GEMM launch
+    assert mod.pmc_traffic_per_launch(32, A) is None     # only the profiled configuration has counters
