@@ -105,3 +105,28 @@ def test_sincos_table_matches_formula():
     assert t.shape == (1, 5, 8)
     pos, j = 3, 5
     assert abs(t[0, pos, j].item() - np.cos(pos / 10000 ** (2 * (j // 2) / 8))) < 1e-6
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under videotransformer-pytorch_amd/ may import or open it;
+    bench.py may use it only inside the cpu_baseline leg and __graft_entry__.py only inside smoke()."""
+    import ast
+    import os
+    from helpers import ROOT
+    def oracle_importers(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            for n in ast.iter_child_nodes(fn) if isinstance(fn, ast.Module) else ast.walk(fn):
+                if isinstance(n, ast.ImportFrom) and (n.module or '').split('.')[0] == 'oracle':
+                    hits.append(getattr(fn, 'name', '<module>'))
+                if isinstance(n, ast.Import) and any(a.name.split('.')[0] == 'oracle' for a in n.names):
+                    hits.append(getattr(fn, 'name', '<module>'))
+        return set(hits)
+    pkg = os.path.join(ROOT, 'videotransformer-pytorch_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                assert not oracle_importers(os.path.join(dirpath, f)), f'{f} imports the oracle'
+    assert oracle_importers(os.path.join(ROOT, 'bench.py')) <= {'cpu_baseline', 'cpu_baseline_subprocess', '_cpu_baseline_main'}
+    assert oracle_importers(os.path.join(ROOT, '__graft_entry__.py')) <= {'smoke'}
