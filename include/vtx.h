@@ -9,12 +9,12 @@
  * Conventions (all entry points):
  *   - extern "C", plain pointers and sizes, no torch types.
  *   - every device pointer is BORROWED for the call; the library never
- *     frees or synchronises, and never allocates except for ONE 576-byte
- *     tile-counter buffer per process that the large bf16 vtx_gemm_nt keeps
- *     (allocated on its first call; its persistent kernel hands out tiles
- *     through it, so such calls must not overlap on two streams); work is
- *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
- *     stream).
+ *     allocates, frees or synchronises (scratch memory comes from the caller:
+ *     vtx_*_workspace() queries); it keeps no mutable state besides the
+ *     tuning switches of vtx_set_option(), so calls may run concurrently on
+ *     different streams / devices as long as their buffers (workspaces
+ *     included) are distinct; work is enqueued on `stream` (a hipStream_t
+ *     passed as void*; NULL = the null stream) of the CURRENT device.
  *   - returns VTX_OK (0) or a negative VTX_E* code; never throws.
  *     vtx_last_error_string() gives the reason for the last failure on the
  *     calling thread.
@@ -55,6 +55,11 @@ typedef struct {
 
 int vtx_version(void);
 const char* vtx_last_error_string(void);
+/* Tuning / diagnostic switches (process-wide; initial values from the VTX_* environment variables,
+ * read once): "gemm_nt" = auto|pp256|dma2|ring128x3|ring128x4k32|ring256x3|ring256x3k32|ring256x4k32,
+ * "gemm_tn" = auto|pp256|ring|dma2, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "pp_grid", "pp_cg",
+ * "pp_epi" = integers, "pp_skew" = float.  Returns VTX_EINVAL for an unknown name or value. */
+int vtx_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------ LayerNorm
  * Replaces nn.LayerNorm in the blocks (transformer.py:215,257 / :321,359 /
@@ -78,7 +83,7 @@ int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, vtx
  * patch gather (:116-126,142,146), MaskFeat decoder_pred
  * (video_transformer.py:855,878).
  * Epilogue order:  v = acc (+bias[n]);  act GELU(erf): C2 = v, v = gelu(v);
- *                  v *= gelu'(dgelu_in[m][n]);  v *= row_scale[idx(m)];  v += bias2[n];
+ *                  v *= gelu'(dgelu_in[m][n]);  v *= row_scale[idx(m)];
  *                  v += R[rmap(m) or m % r_period][n];  C[cmap(m)][n] = v.
  * Rows m >= split_row (if split_row > 0) are stored to Csplit[m - split_row]
  * with bias/act/scale applied but no residual (the per-frame cls rows of the
@@ -97,8 +102,11 @@ typedef struct {
   int rs_d1, rs_m1, rs_d2, rs_m2;     /* idx(m) = (m / rs_d1) * rs_m1 + (m % rs_d2) * rs_m2 */
   const void* R; long ldr; vtx_rowmap rmap; int r_period; /* residual; r_period>0: row m % r_period */
   int split_row; void* Csplit; long ldsplit;
-  const float* bias2;                 /* [N] added AFTER the row scale (a bias behind DropPath), or NULL */
+  void* workspace; size_t ws_bytes;   /* vtx_gemm_nt_workspace() bytes, ZEROED once by the caller and private to the
+                                         stream the call runs on: tile counters of the persistent bf16 kernel, which
+                                         leaves them zeroed.  NULL selects the non-persistent kernels. */
 } vtx_gemm_desc;
+size_t vtx_gemm_nt_workspace(void);
 int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream);
 
 /* Weight gradient: C[N1,N2] (fp32) (+)= sum_m A[amap(m)][n1] * B[bmap(m)][n2].

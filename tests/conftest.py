@@ -22,3 +22,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+_OPTION_DEFAULTS = dict(gemm_nt='auto', gemm_tn='auto', gemm_nodma='0', tn_safe='0', attn_valu='0', pp_grid='256',
+                        pp_cg='0', pp_epi='0', pp_skew='1')
+
+
+@pytest.fixture
+def vtx_opts():
+    """set(name, value) -> vtx.set_option; every touched switch is put back to its default afterwards."""
+    import vtx
+    touched = set()
+
+    def set_(name, value):
+        vtx.set_option(name, value)
+        touched.add(name)
+    yield set_
+    for name in touched:
+        vtx.set_option(name, _OPTION_DEFAULTS[name])

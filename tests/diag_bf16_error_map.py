@@ -31,7 +31,7 @@ def run(prec, frames, env):
     import vtx
     import video_transformer as V
     for k, v in env.items():
-        os.environ[k] = v
+        vtx.set_option(k, v)
     vtx.set_precision(prec)
     vtx.functions.clear_weight_cache()
     m = V.TimeSformer(num_frames=frames)
@@ -54,15 +54,15 @@ def run(prec, frames, env):
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None}
     for k in env:
-        os.environ.pop(k, None)
+        vtx.set_option(k, 'auto' if k.startswith('gemm') else '0')
     return y.detach().float().cpu(), fwd, bwd, grads
 
 
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     y0, f0, b0, g0 = run('fp32', frames, {})
-    variants = [('bf16 default', {}), ('bf16 VTX_ATTN_VALU=1', {'VTX_ATTN_VALU': '1'}),
-                ('bf16 VTX_GEMM_NT=dma2 VTX_GEMM_TN=dma2', {'VTX_GEMM_NT': 'dma2', 'VTX_GEMM_TN': 'dma2'})]
+    variants = [('bf16 default', {}), ('bf16 attn_valu=1', {'attn_valu': '1'}),
+                ('bf16 gemm_nt=dma2 gemm_tn=dma2', {'gemm_nt': 'dma2', 'gemm_tn': 'dma2'})]
     for name, env in variants:
         y, f, b, g = run('bf16', frames, env)
         print(f'==== {name}: out max-rel {(y - y0).abs().max().item() / y0.abs().max().item():.3e}  l2 {l2(y, y0):.3e}')

@@ -102,3 +102,15 @@ def test_bench_traffic_helper_reads_committed_pmc_passes():
     t = mod.pmc_traffic_per_launch(64, A)
     assert t is not None and 2e8 < t < 5e9, t            # a few hundred MB .. a few GB per GEMM launch
     assert mod.pmc_traffic_per_launch(32, A) is None     # only the profiled configuration has counters
+
+
+def test_options_api():
+    """vtx_set_option: known switches parse, unknown names / values are rejected (no GPU needed)."""
+    import vtx
+    vtx.set_option('gemm_nt', 'ring256x3')
+    vtx.set_option('gemm_nt', 'auto')
+    vtx.set_option('pp_grid', '64')
+    vtx.set_option('pp_grid', '256')
+    for name, value in (('gemm_nt', 'nope'), ('no_such_switch', '1'), ('pp_grid', '7')):
+        with pytest.raises(vtx.VtxError):
+            vtx.set_option(name, value)

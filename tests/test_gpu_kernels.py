@@ -83,10 +83,10 @@ def test_layernorm_fwd_bwd(dtype, D):
 
 # --------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('variant', ['pp256', 'ring256x3', 'ring256x3k32', 'ring256x4k32', 'ring128x3', 'ring128x4k32', 'dma2'])
-def test_gemm_nt_bf16_variants(variant, monkeypatch):
+def test_gemm_nt_bf16_variants(variant, vtx_opts):
     """Every staging variant of the bf16 NT GEMM (2-buffer DMA, DMA rings with counted vmcnt)."""
     from vtx import ops
-    monkeypatch.setenv('VTX_GEMM_NT', variant)
+    vtx_opts('gemm_nt', variant)
     for (M, N, K) in [(1568, 2304, 768), (3000, 216, 3072), (1030, 768, 192), (12544, 768, 768), (777, 1000, 128)]:
         A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
         ref = q(A, torch.bfloat16) @ q(W, torch.bfloat16).t() + b.double()
@@ -97,23 +97,23 @@ def test_gemm_nt_bf16_variants(variant, monkeypatch):
             # the persistent kernel draws tiles from per-XCD counters: any grid (= any number of resident
             # workgroups) must produce the same result, and the counters must be left clean for the next launch
             for grid in ('40', '8', '256'):
-                monkeypatch.setenv('VTX_GEMM_PP_GRID', grid)
+                vtx_opts('pp_grid', grid)
                 C2 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
                 ops.gemm_nt(dev(A, torch.bfloat16), dev(W, torch.bfloat16), C2, M, N, K, bias=dev(b))
                 assert torch.equal(C2, C), f'pp256 grid {grid}: result depends on the grid size'
-            monkeypatch.delenv('VTX_GEMM_PP_GRID')
+            vtx_opts('pp_grid', '256')
 
 
 @pytest.mark.parametrize('nodma', ['0', '1'])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1568, 2304, 768), (130, 216, 768), (257, 768, 96), (64, 8, 8),
                                    (12544, 768, 3072)])
-def test_gemm_nt_plain(dtype, M, N, K, nodma, monkeypatch):
+def test_gemm_nt_plain(dtype, M, N, K, nodma, vtx_opts):
     """nodma=0: LDS-DMA staged kernel when K % 64 == 0 (bf16); nodma=1: register-staged kernel."""
     from vtx import ops
     if nodma == '1' and dtype == torch.float32:
         pytest.skip('fp32 has a single kernel')
-    monkeypatch.setenv('VTX_GEMM_NODMA', nodma)
+    vtx_opts('gemm_nodma', nodma)
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
     ref = q(A, dtype) @ q(W, dtype).t() + b.double()
     C = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
@@ -177,23 +177,126 @@ def test_gemm_nt_epilogues(dtype):
     check(f'gemm split cls rows {dtype}', a_cls.float().cpu(), ref_cls, TOL[dtype])
 
 
+@pytest.mark.parametrize('epi', ['0', '1'])
+@pytest.mark.parametrize('Hd', [256, 320])
+def test_gemm_nt_pp_epilogues(Hd, epi, vtx_opts):
+    """Every fused epilogue of the persistent 256x256 bf16 kernel (M >= 2048: the path the benchmark runs), with
+    full and ragged column tiles, many tiles per workgroup (grid 8) and both epilogue structures
+    (pp_epi=0: all epilogue reads ahead of the tile's stores, residual block staged through LDS;
+    pp_epi=1: per-pass reads).  Reference: float64 on the CPU from the bf16-rounded operands."""
+    from vtx import ops
+    dtype = torch.bfloat16
+    vtx_opts('gemm_nt', 'pp256')
+    vtx_opts('pp_epi', epi)
+    B, P, T, D = 3, 196, 4, 128                    # N = 784 tokens per clip, M = 2352 rows (10 row tiles, last ragged)
+    N = P * T
+    M = B * N
+    tm = ops.tokmap(N)
+    A, W, bias = rnd(M, D, seed=1), rnd(Hd, D, seed=2) * D ** -0.5, rnd(Hd, seed=3)
+    Aq, Wq = q(A, dtype), q(W, dtype)
+    for grid in ('256', '8'):
+        vtx_opts('pp_grid', grid)
+        tag = f'pp epi={epi} N={Hd} grid={grid}'
+        # (1) bias + GELU with pre-activation copy
+        pre = Aq @ Wq.t() + bias.double()
+        C = torch.full((M, Hd), float('nan'), dtype=dtype, device=DEV)
+        C2 = torch.full((M, Hd), float('nan'), dtype=dtype, device=DEV)
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, bias=dev(bias), act=1, C2=C2)
+        check(f'{tag} gelu', C.float().cpu(), torch.nn.functional.gelu(pre), 1e-2)
+        check(f'{tag} preact', C2.float().cpu(), pre, 1e-2)
+        # (2) GELU' multiply (FFN backward)
+        h = rnd(M, Hd, seed=4)
+        hq = q(h, dtype).requires_grad_(True)
+        torch.nn.functional.gelu(hq).sum().backward()
+        C.fill_(float('nan'))
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, dgelu_in=dev(h, dtype))
+        check(f'{tag} dgelu', C.float().cpu(), (Aq @ Wq.t()) * hq.grad, 1e-2)
+        # (3) A rows through the token map, per-(b,p) row scale, residual + output through the map
+        X, R = rnd(B, 1 + N, D, seed=5), rnd(B, 1 + N, Hd, seed=6)
+        s = (torch.rand(M // T, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7
+        ref = (q(X, dtype)[:, 1:].reshape(M, D) @ Wq.t() + bias.double()) * s.double().repeat_interleave(T)[:, None]
+        ref = ref.reshape(B, N, Hd) + q(R, dtype)[:, 1:]
+        out = torch.zeros(B, 1 + N, Hd, dtype=dtype, device=DEV)
+        ops.gemm_nt(dev(X, dtype), dev(W, dtype), out, M, Hd, D, amap=tm, cmap=tm, bias=dev(bias), row_scale=dev(s),
+                    rs=(T, 1, 1, 0), R=dev(R, dtype), rmap=tm)
+        check(f'{tag} map+scale+residual', out.float().cpu()[:, 1:], ref, 1e-2)
+        assert out[:, 0].abs().max().item() == 0, 'cls rows must not be touched'
+        # (3b) row scale without a residual, residual without a row scale
+        C.fill_(float('nan'))
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, bias=dev(bias), row_scale=dev(s), rs=(T, 1, 1, 0))
+        check(f'{tag} scale only', C.float().cpu(), (Aq @ Wq.t() + bias.double()) * s.double().repeat_interleave(T)[:, None], 1e-2)
+        out.zero_()
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), out, M, Hd, D, cmap=tm, bias=dev(bias), R=dev(R, dtype), rmap=tm)
+        check(f'{tag} residual only', out.float().cpu()[:, 1:], (Aq @ Wq.t() + bias.double()).reshape(B, N, Hd) + q(R, dtype)[:, 1:], 1e-2)
+        # (4) periodic residual (embedding table)
+        E = rnd(N, Hd, seed=8)
+        out.zero_()
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), out, M, Hd, D, cmap=tm, R=dev(E, dtype), r_period=N)
+        check(f'{tag} periodic residual', out.float().cpu()[:, 1:], (Aq @ Wq.t()).reshape(B, N, Hd) + q(E, dtype)[None], 1e-2)
+        # (5) split output region + spatial scale indexing (tokens (b, p*T+t) -> s[b*T+t]; tail rows -> s[row])
+        Mo = M + B * T
+        A2 = rnd(Mo, D, seed=9)
+        s2 = (torch.rand(B * T, generator=torch.Generator().manual_seed(10)) > 0.3).float() / 0.7
+        full = q(A2, dtype) @ Wq.t() + bias.double()
+        n_idx = torch.arange(M)
+        tok_scale = s2.double()[(n_idx // N) * T + (n_idx % T)]
+        ref_tok = (full[:M] * tok_scale[:, None]).reshape(B, N, Hd) + q(R, dtype)[:, 1:]
+        out.zero_()
+        a_cls = torch.full((B * T, Hd), float('nan'), dtype=dtype, device=DEV)
+        ops.gemm_nt(dev(A2, dtype), dev(W, dtype), out, Mo, Hd, D, cmap=tm, bias=dev(bias), row_scale=dev(s2),
+                    rs=(N, T, T, 1), R=dev(R, dtype), rmap=tm, split_row=M, Csplit=a_cls)
+        check(f'{tag} split tokens', out.float().cpu()[:, 1:], ref_tok, 1e-2)
+        check(f'{tag} split cls rows', a_cls.float().cpu(), full[M:] * s2.double()[:, None], 1e-2)
+
+
+def test_gemm_nt_pp_epilogue_structures_agree(vtx_opts):
+    """The two epilogue structures of the persistent kernel are the same arithmetic in the same order: bit-identical
+    outputs; and a second stream (its own tile-counter workspace) gives the same result concurrently."""
+    from vtx import ops
+    dtype = torch.bfloat16
+    vtx_opts('gemm_nt', 'pp256')
+    M, N, K = 5000, 768, 256
+    A, W, b = dev(rnd(M, K, seed=1), dtype), dev(rnd(N, K, seed=2) * K ** -0.5, dtype), dev(rnd(N, seed=3))
+    R = dev(rnd(M, N, seed=4), dtype)
+    s = dev((torch.rand(M, generator=torch.Generator().manual_seed(5)) > 0.3).float() / 0.7)
+    outs = []
+    for epi in ('0', '1'):
+        vtx_opts('pp_epi', epi)
+        C = torch.empty(M, N, dtype=dtype, device=DEV)
+        ops.gemm_nt(A, W, C, M, N, K, bias=b, row_scale=s, R=R)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    vtx_opts('pp_epi', '0')
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    C_main = torch.empty(M, N, dtype=dtype, device=DEV)
+    C_side = torch.empty(M, N, dtype=dtype, device=DEV)
+    for _ in range(3):
+        ops.gemm_nt(A, W, C_main, M, N, K, bias=b, row_scale=s, R=R)
+        with torch.cuda.stream(side):
+            ops.gemm_nt(A, W, C_side, M, N, K, bias=b, row_scale=s, R=R)
+    torch.cuda.synchronize()
+    assert torch.equal(C_main, outs[0]) and torch.equal(C_side, outs[0])
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304), (12552, 768, 768),
                                      (1031, 216, 768), (4099, 3072, 768), (1024, 8, 136), (4131, 1024, 1280)])
-def test_gemm_tn(dtype, M, N1, N2, monkeypatch):
+def test_gemm_tn(dtype, M, N1, N2, vtx_opts):
     from vtx import ops
     A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
     ref = q(A, dtype).t() @ q(Bm, dtype)
     for safe, nodma, tnv in ([('0', '0', 'pp256'), ('0', '0', 'ring'), ('0', '0', 'dma2'), ('0', '1', 'ring'), ('1', '1', 'ring')]
                              if dtype == torch.bfloat16 else [('0', '0', 'ring')]):
-        monkeypatch.setenv('VTX_TN_SAFE', safe)
-        monkeypatch.setenv('VTX_GEMM_NODMA', nodma)
-        monkeypatch.setenv('VTX_GEMM_TN', tnv)
+        vtx_opts('tn_safe', safe)
+        vtx_opts('gemm_nodma', nodma)
+        vtx_opts('gemm_tn', tnv)
         C, cs = ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2, want_colsum=True)
         check(f'gemm_tn {dtype} safe={safe} nodma={nodma} {tnv} {M}x{N1}x{N2}', C.cpu(), ref, 2e-3 if dtype == torch.bfloat16 else 1e-3)
         check(f'gemm_tn colsum {dtype} safe={safe} nodma={nodma} {M}x{N1}x{N2}', cs.cpu(), q(A, dtype).sum(0), 1e-3)
-    monkeypatch.setenv('VTX_TN_SAFE', '0')
-    monkeypatch.setenv('VTX_GEMM_NODMA', '0')
+    vtx_opts('tn_safe', '0')
+    vtx_opts('gemm_nodma', '0')
+    vtx_opts('gemm_tn', 'auto')
     C0 = torch.ones(N1, N2, device=DEV)
     ops.gemm_tn(dev(A, dtype), dev(Bm, dtype), M, N1, N2, out=C0, accumulate=True)
     check(f'gemm_tn accumulate {dtype}', C0.cpu(), ref + 1, 2e-3)
@@ -302,7 +405,7 @@ def test_attention_space_mode(dtype, B, T, P):
 
 
 @pytest.mark.parametrize('S,L', [(3, 197), (37, 8), (5, 9), (7, 16), (4, 32), (3, 33), (1, 256), (9, 1), (6, 5)])
-def test_attention_mfma_matches_valu(S, L, monkeypatch):
+def test_attention_mfma_matches_valu(S, L, vtx_opts):
     """The bf16 MFMA kernels (packed short sequences / 33..256 tokens) and the VALU kernels are
     two implementations of the same op."""
     from vtx import ops
@@ -313,7 +416,7 @@ def test_attention_mfma_matches_valu(S, L, monkeypatch):
     do = dev(rnd(S, L, D, seed=6), torch.bfloat16)
     res = {}
     for mode in ('1', '0'):
-        monkeypatch.setenv('VTX_ATTN_VALU', mode)
+        vtx_opts('attn_valu', mode)
         o = torch.empty(S, L, D, dtype=torch.bfloat16, device=DEV)
         lse = torch.empty(S * H * L, device=DEV)
         ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)

@@ -162,28 +162,6 @@ def test_batch_and_length_properties():
     check('clip independence (bf16, B=3 vs B=1)', y1.cpu(), y3[1:2].cpu(), 1e-6)
 
 
-def test_fused_proj_tfc_matches_unfused(monkeypatch):
-    """VTX_FUSE_PROJ_TFC=1 (proj . temporal_fc folded into one GEMM, bias behind DropPath through the
-    epilogue's bias2) is the same function and the same gradients as the literal two-GEMM structure."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision('fp32')
-    outs = []
-    for fuse in ('0', '1'):
-        monkeypatch.setenv('VTX_FUSE_PROJ_TFC', fuse)
-        m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
-        m.train()
-        x = synth.synth_clip(2, 4, 3, 64, 64, seed=5).to(DEV)
-        torch.manual_seed(0)                       # same DropPath draws
-        y = m(x)
-        (y.float() ** 2).sum().backward()
-        outs.append((y.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}))
-    check('fused proj.tfc output', outs[1][0], outs[0][0], 1e-4)
-    for n in outs[0][1]:
-        if 'proj' in n or 'temporal_fc' in n or 'qkv' in n:
-            check(f'fused proj.tfc grad {n}', outs[1][1][n], outs[0][1][n], 1e-3)
-
-
 def test_uint8_clip_input_equals_float_input():
     """A decoded uint8 [B,T,H,W,3] clip fed to the model (vtx.set_input_normalization) gives exactly the
     output of the reference-style float [B,T,C,H,W] input produced by ToTensor + Normalize."""

@@ -3,6 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'videotransformer-pytorch_amd'), os.path.join(ROOT, 'tools')):
     sys.path.insert(0, p)
 import torch
+import vtx
 from vtx import ops
 from kernel_bench import timeit
 M = 100352
@@ -12,7 +13,7 @@ for (N, K) in ((3072, 768), (2304, 768), (768, 3072), (768, 2304), (768, 768)):
     c = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
     res = []
     for cg in (1, 2, 3, 4, 6, 8, 12):
-        os.environ['VTX_GEMM_PP_CG'] = str(cg)
+        vtx.set_option('pp_cg', str(cg))
         t = timeit(lambda: ops.gemm_nt(a, w, c, M, N, K))
         res.append(f'cg{cg}={t*1e6:.0f}us/{2.0*M*N*K/t/1e12:.0f}TF')
     print(f'N={N} K={K}: ' + ' '.join(res), flush=True)

@@ -5,13 +5,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'videotransformer-pytorch_amd'), os.path.join(ROOT, 'tools')):
     sys.path.insert(0, p)
 import torch
+import vtx
 from vtx import ops
 from kernel_bench import timeit
-os.environ['VTX_GEMM_NT'] = 'pp256'
-os.environ['VTX_GEMM_PP_SKEW'] = '0'
+vtx.set_option('gemm_nt', 'pp256')
+vtx.set_option('pp_skew', '0')
 N, K = 3072, 768
 for grid, M in ((8, 2048), (64, 2048 * 8), (256, 2048 * 32)):
-    os.environ['VTX_GEMM_PP_GRID'] = str(grid)
+    vtx.set_option('pp_grid', str(grid))
     a = torch.randn(M, K, device='cuda').bfloat16()
     w = torch.randn(N, K, device='cuda').bfloat16()
     c = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)

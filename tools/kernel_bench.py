@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'videotransformer-pytorch_amd')):
     sys.path.insert(0, p)
 import torch  # noqa: E402
+import vtx  # noqa: E402
 from vtx import ops  # noqa: E402
 from vtx._lib import ATTN_CONTIG, ATTN_SPACE  # noqa: E402
 
@@ -40,10 +41,10 @@ def main():
             A, W, C = r(M, K), r(Nn, K), torch.empty(M, Nn, device=DEV, dtype=dtype)
             bias = torch.randn(Nn, device=DEV)
             for variant in (['dma2', 'ring128x4k32', 'ring256x3', 'ring256x3k32', 'ring256x4k32'] if dtype == torch.bfloat16 else ['-']):
-                os.environ['VTX_GEMM_NT'] = variant
+                vtx.set_option('gemm_nt', variant)
                 t = timeit(lambda: ops.gemm_nt(A, W, C, M, Nn, K, bias=bias))
                 print(f'gemm_nt {name} {tag:5s} {variant:9s} M={M} N={Nn} K={K}: {t*1e6:8.1f} us  {2*M*Nn*K/t/1e12:7.1f} TFLOP/s', flush=True)
-            os.environ.pop('VTX_GEMM_NT', None)
+            vtx.set_option('gemm_nt', 'auto')
         for (M, N1, N2, tag) in [(B * N, 3 * D, D, 'dWqkv'), (B * N, D, D, 'dWproj'), (B * (N + 1), 4 * D, D, 'dWffn1'),
                                  (B * (N + 1), D, 4 * D, 'dWffn2')]:
             if dtype == torch.float32 and tag != 'dWqkv':
@@ -51,10 +52,10 @@ def main():
             A, Bm = r(M, N1), r(M, N2)
             out = torch.empty(N1, N2, device=DEV)
             for variant in (['dma2', 'ring'] if dtype == torch.bfloat16 else ['-']):
-                os.environ['VTX_GEMM_TN'] = variant
+                vtx.set_option('gemm_tn', variant)
                 t = timeit(lambda: ops.gemm_tn(A, Bm, M, N1, N2, out=out, want_colsum=True))
                 print(f'gemm_tn {name} {tag:6s} {variant:5s} M={M} N1={N1} N2={N2}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TFLOP/s', flush=True)
-            os.environ.pop('VTX_GEMM_TN', None)
+            vtx.set_option('gemm_tn', 'auto')
         es = 2 if dtype == torch.bfloat16 else 4
         # attention cores
         qkv = r(B * N, 3 * D)

@@ -1,5 +1,6 @@
 // api.hip -- error plumbing, version, and the instruction-layout self-test.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -23,6 +24,45 @@ int check_launch(const char* what) {
     return VTX_ELAUNCH;
   }
   return VTX_OK;
+}
+
+// ---- options -------------------------------------------------------------------------
+static const char* const kNtNames[] = {"auto", "pp256", "dma2", "ring128x3", "ring128x4k32", "ring256x3", "ring256x3k32", "ring256x4k32"};
+static const char* const kTnNames[] = {"auto", "pp256", "ring", "dma2"};
+
+static int parse_enum(const char* v, const char* const* names, int n) {
+  for (int i = 0; i < n; ++i)
+    if (strcmp(v, names[i]) == 0) return i;
+  return -1;
+}
+
+static int set_option(Options& o, const char* name, const char* value) {
+  if (!name || !value) return VTX_EINVAL;
+  if (strcmp(name, "gemm_nt") == 0) { const int e = parse_enum(value, kNtNames, 8); if (e < 0) return VTX_EINVAL; o.gemm_nt = e; return VTX_OK; }
+  if (strcmp(name, "gemm_tn") == 0) { const int e = parse_enum(value, kTnNames, 4); if (e < 0) return VTX_EINVAL; o.gemm_tn = e; return VTX_OK; }
+  if (strcmp(name, "gemm_nodma") == 0) { o.gemm_nodma = atoi(value) != 0; return VTX_OK; }
+  if (strcmp(name, "tn_safe") == 0) { o.tn_safe = atoi(value) != 0; return VTX_OK; }
+  if (strcmp(name, "attn_valu") == 0) { o.attn_valu = atoi(value) != 0; return VTX_OK; }
+  if (strcmp(name, "pp_grid") == 0) { const int g = atoi(value); if (g < 8 || g > 4096 || g % 8) return VTX_EINVAL; o.pp_grid = g; return VTX_OK; }
+  if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }
+  if (strcmp(name, "pp_epi") == 0) { o.pp_epi = atoi(value); return VTX_OK; }
+  if (strcmp(name, "pp_skew") == 0) { o.pp_skew = (float)atof(value); return VTX_OK; }
+  return VTX_EINVAL;
+}
+
+Options& options() {
+  static Options o = [] {
+    Options d;
+    static const char* const env[][2] = {{"VTX_GEMM_NT", "gemm_nt"}, {"VTX_GEMM_TN", "gemm_tn"}, {"VTX_GEMM_NODMA", "gemm_nodma"},
+                                         {"VTX_TN_SAFE", "tn_safe"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
+                                         {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"}, {"VTX_GEMM_PP_SKEW", "pp_skew"}};
+    for (const auto& e : env) {
+      const char* v = getenv(e[0]);
+      if (v && *v) set_option(d, e[1], v);       // an unparsable value keeps the default
+    }
+    return d;
+  }();
+  return o;
 }
 
 // ---- probes (one wave each) ---------------------------------------------------------
@@ -63,7 +103,13 @@ __global__ void probe_tr(unsigned short* out) {
 
 using namespace vtx;
 
-extern "C" int vtx_version(void) { return 100; }  // 0.1.0
+extern "C" int vtx_version(void) { return 200; }  // 0.2.0
+
+extern "C" int vtx_set_option(const char* name, const char* value) {
+  const int rc = set_option(options(), name, value);
+  if (rc) set_error("vtx_set_option: unknown option or bad value: %s=%s", name ? name : "(null)", value ? value : "(null)");
+  return rc;
+}
 extern "C" const char* vtx_last_error_string(void) { return g_err; }
 
 extern "C" int vtx_selftest(char* report, size_t report_bytes) {

@@ -299,14 +299,12 @@ __global__ __launch_bounds__(AT_THREADS, 1) void attn_bwd_dkv_kernel(AttnP p, co
 
 // bf16, head_dim 64, 33..256 tokens -> MFMA kernels (attn_mfma.hip); VTX_ATTN_VALU=1 forces the VALU path.
 static bool use_mfma(int dtype, int L, int hd) {
-  const char* e = getenv("VTX_ATTN_VALU");
-  if (e && atoi(e) != 0) return false;
+  if (options().attn_valu) return false;
   return attn_mfma_eligible(dtype, L, hd);
 }
 
 static bool use_small(int dtype, int mode, int L, int hd) {
-  const char* e = getenv("VTX_ATTN_VALU");
-  if (e && atoi(e) != 0) return false;
+  if (options().attn_valu) return false;
   return attn_small_eligible(dtype, mode, L, hd);
 }
 

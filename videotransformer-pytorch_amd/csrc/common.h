@@ -10,6 +10,7 @@ namespace vtx {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef unsigned short bf16raw;  // storage type of a bf16 element
@@ -127,6 +128,24 @@ __device__ inline float gelu_erf_grad(float x) {
   const float xs = x * 0.3989422804014327f;
   return fmaf(xs, g, cdf);
 }
+
+// ---- tuning / diagnostic switches ----------------------------------------------------
+// Process-wide, set through vtx_set_option() (initial values come from the VTX_* environment
+// variables, read ONCE when the library is first used -- never on the launch path).
+enum { NT_AUTO = 0, NT_PP256, NT_DMA2, NT_RING128X3, NT_RING128X4K32, NT_RING256X3, NT_RING256X3K32, NT_RING256X4K32 };
+enum { TN_AUTO = 0, TN_PP256, TN_RING, TN_DMA2 };
+struct Options {
+  int gemm_nt = NT_AUTO;     // VTX_GEMM_NT: kernel family override of vtx_gemm_nt (bf16)
+  int gemm_tn = TN_AUTO;     // VTX_GEMM_TN: ... of vtx_gemm_tn (bf16)
+  int gemm_nodma = 0;        // VTX_GEMM_NODMA: register-staged GEMM kernels (no LDS-DMA)
+  int tn_safe = 0;           // VTX_TN_SAFE: bounds-checked TN loader (diagnostic)
+  int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
+  int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
+  int pp_cg = 0;             // VTX_GEMM_PP_CG: column tiles per group (0: from K)
+  int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing of the batched one)
+  float pp_skew = 1.0f;      // VTX_GEMM_PP_SKEW: start-skew scale of the persistent NT GEMM
+};
+Options& options();
 
 // ---- host-side error plumbing --------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -18,7 +18,6 @@ struct EpiParams {
   const float* row_scale; int rs_d1, rs_m1, rs_d2, rs_m2;
   const void* R; long ldr; vtx_rowmap rmap; int r_period;
   int split_row; void* Csplit; long ldsplit;
-  const float* bias2;
 };
 
 // XCD-aware bijective remap of the linear block id (8 XCDs, block b runs on XCD b%8):
@@ -117,15 +116,6 @@ __device__ inline void epilogue(const EpiParams& p, const float* stage, int m_ba
       for (int u = 0; u < UB; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[u][j] *= sc[u];
-    }
-    if (p.bias2) {
-      const float4 c0 = *reinterpret_cast<const float4*>(p.bias2 + n);
-      const float4 c1 = *reinterpret_cast<const float4*>(p.bias2 + n + 4);
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        v[u][0] += c0.x; v[u][1] += c0.y; v[u][2] += c0.z; v[u][3] += c0.w;
-        v[u][4] += c1.x; v[u][5] += c1.y; v[u][6] += c1.z; v[u][7] += c1.w;
-      }
     }
     if (p.R) {
       float r8[UB][8];

@@ -17,8 +17,6 @@
 // fused bias / GELU / GELU' / DropPath-scale / residual / row-scatter run on
 // row-contiguous 8-element vectors, independent of the MFMA register layout.
 // Algorithmic FLOPs per launch: 2*M*N*K.
-#include <stdlib.h>
-#include <string>
 #include "gemm_common.h"
 
 namespace vtx {
@@ -324,7 +322,7 @@ static int launch_ring(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   const size_t lds = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_ring_kernel<WM, NBUF, BK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_ring_kernel<WM, NBUF, BK>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -372,6 +370,7 @@ __device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory
 // epilogue stages through its own 32 KB of LDS, and its stores drain under the next main loop.
 // (vmcnt counts loads and stores together; a counted wait can therefore over-wait on stores but never
 // under-wait on the DMA, because loads retire in order among themselves.)
+template <bool EPI2, bool HAS_PRE, bool HAS_SC>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, int* __restrict__ tile_ctr,
@@ -415,15 +414,21 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     }
   };
   if (xcount == 0) { check_out(); return; }
-  volatile int* const bcast = reinterpret_cast<volatile int*>(smem + PP_RING_BYTES);   // staging is idle between epilogues
-  auto next_tile = [&]() -> int {                // every wave is between tiles (no LDS traffic, groups aligned)
-    if (tid == 0) *bcast = atomicAdd(my_ctr, 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* const bcast = (lds_int*)(smem + PP_RING_BYTES);              // staging is idle between epilogues
+  auto publish = [&](int v) -> int {             // lane 0 of the workgroup -> every wave (all waves are between tiles)
+    if (tid == 0) *bcast = v;
+    lgkm0();
     __builtin_amdgcn_s_barrier();
     const int t = *bcast;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lgkm0();
     __builtin_amdgcn_s_barrier();                // the word may be overwritten (epilogue staging) only after all have read it
     return __builtin_amdgcn_readfirstlane(t);
+  };
+  auto next_tile = [&]() -> int {                // draw and publish in one step: the atomic's round trip is exposed
+    int v = 0;
+    if (tid == 0) v = atomicAdd(my_ctr, 1);
+    return publish(v);
   };
   // De-synchronise the CUs.  Every tile takes the same time, so all 256 workgroups would reach their
   // epilogues together and share HBM's write bandwidth for the 128-KB C tiles (measured: the stores
@@ -503,6 +508,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   int t = next_tile();
   const int tend = xcount;
   if (t >= tend) { check_out(); return; }
+  int pending = 0;                               // EPI2: index drawn for the tile after `t` (lane 0 of the workgroup)
+  if (EPI2 && tid == 0) pending = atomicAdd(my_ctr, 1);
   set_tile(t);
   prologue();
   while (true) {
@@ -553,25 +560,170 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
     const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
-    t = next_tile();
-    const bool more = t < tend;
-    if (more) { set_tile(t); prologue(); }        // ring is free: request the next tile before the epilogue
-    // eight 16-row passes, expanded by hand: a loop here makes the compiler index acc[] dynamically
-    // (= the whole accumulator goes through scratch)
+    if constexpr (!EPI2) {
+      t = next_tile();
+      const bool more = t < tend;
+      if (more) { set_tile(t); prologue(); }        // ring is free: request the next tile before the epilogue
+      // eight 16-row passes, expanded by hand: a loop here makes the compiler index acc[] dynamically
+      // (= the whole accumulator goes through scratch)
 #define PP_EPI(mi_, half_)                                                                              \
-    {                                                                                                   \
-      const int col = lane & 31, rhalf = (lane >> 5) * 4;                                               \
-      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)    \
-          stg[((r & 3) + 8 * (r >> 2) + rhalf) * PP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r]; \
-      lgkm0();                                                                                          \
-      __builtin_amdgcn_wave_barrier();                                                                  \
-      epilogue<bf16raw, 16, 2, PP_STG_LD>(ep, stg, em0 + (mi_) * 32 + (half_) * 16, en0, lane);         \
-      lgkm0();                                                                                          \
-      __builtin_amdgcn_wave_barrier();                                                                  \
-    }
-    PP_EPI(0, 0) PP_EPI(0, 1) PP_EPI(1, 0) PP_EPI(1, 1) PP_EPI(2, 0) PP_EPI(2, 1) PP_EPI(3, 0) PP_EPI(3, 1)
+      {                                                                                                 \
+        const int col = lane & 31, rhalf = (lane >> 5) * 4;                                             \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)  \
+            stg[((r & 3) + 8 * (r >> 2) + rhalf) * PP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r]; \
+        lgkm0();                                                                                        \
+        __builtin_amdgcn_wave_barrier();                                                                \
+        epilogue<bf16raw, 16, 2, PP_STG_LD>(ep, stg, em0 + (mi_) * 32 + (half_) * 16, en0, lane);       \
+        lgkm0();                                                                                        \
+        __builtin_amdgcn_wave_barrier();                                                                \
+      }
+      PP_EPI(0, 0) PP_EPI(0, 1) PP_EPI(1, 0) PP_EPI(1, 1) PP_EPI(2, 0) PP_EPI(2, 1) PP_EPI(3, 0) PP_EPI(3, 1)
 #undef PP_EPI
-    if (!more) break;
+      if (!more) break;
+    } else {
+      // The index of the next tile was drawn one tile ago (`pending`): publishing it costs two barriers,
+      // not an atomic round trip; the draw for the tile after it goes out below and returns under the
+      // epilogue's own load latency.
+      t = publish(pending);
+      const bool more = t < tend;
+      // Every global READ of the epilogue happens HERE, before the tile's first store.  vmcnt counts loads and
+      // stores together and a wait can only name "all but the N youngest": a load waited for inside the store
+      // passes drains every store issued before it.  (The per-pass epilogue above does that eight times per
+      // tile -- `s_waitcnt vmcnt(0)` ahead of each pass's bias / scale / residual use -- so the 128-KB C tile
+      // leaves at store LATENCY: measured 14 us per tile, 24..28 us with a residual, against a 17 us main loop at
+      // K = 768.)
+      //   bias: 8 registers; DropPath scales of the lane's 16 rows: 16 registers;
+      //   residual / GELU' input of the wave's 128 x 64 block: 16 KB -- too many registers beside the 128
+      //   accumulators, so it goes through LDS: 16 LDS-DMA pieces into the wave's slice of the (idle) operand
+      //   ring.  The next tile's prologue then has to wait for the passes to finish reading it (one extra
+      //   barrier; ~1.5 us of prologue latency exposed instead of ~10 us of store latency).
+      const int en = en0 + (lane & 7) * 8;
+      const bool col_ok = en < ep.N;
+      const int enc = col_ok ? en : 0;
+      const int er = em0 + (lane >> 3);            // row of pass p, half-row u: er + 16 p + 8 u
+      const bool pre_res = ep.R != nullptr;
+      bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: lane-linear per piece
+      if constexpr (HAS_PRE) {
+        const bf16raw* const pre_base = reinterpret_cast<const bf16raw*>(pre_res ? ep.R : ep.dgelu_in);
+        const long pre_ld = pre_res ? ep.ldr : ep.ld_dgelu;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {             // piece j = rows 8j .. 8j+7 of the block; lane -> row 8j + lane/8, chunk lane%8
+          int ml = er + 8 * j;
+          if (ml >= ep.M) ml = ep.M - 1;           // always-valid addresses; only the stores are predicated
+          long rr = ml;
+          if (pre_res) {
+            const bool split = ep.split_row > 0 && ml >= ep.split_row;      // split rows take no residual: read row 0
+            rr = split ? 0 : (ep.r_period > 0 ? (long)(ml % ep.r_period) : map_row(ep.rmap, ml));
+          }
+          dma16(pre_base + rr * pre_ld + enc, pre_lds + j * 512);
+        }
+      }
+      // bias in the ACCUMULATOR layout (a lane owns one column of each 32-column half: 2 registers instead of the 8 a
+      // row-vector lane needs, and 64 adds per tile instead of 128); same fp32 add, same result
+      float bcol[2] = {0.f, 0.f};
+      if (ep.bias) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int c = en0 + ni * 32 + (lane & 31);
+          bcol[ni] = ep.bias[c < ep.N ? c : 0];
+        }
+      }
+      float sc[8][2];
+      if constexpr (HAS_SC) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            int ml = er + 16 * p + 8 * u;
+            if (ml >= ep.M) ml = ep.M - 1;
+            const bool split = ep.split_row > 0 && ml >= ep.split_row;
+            sc[p][u] = ep.row_scale[split ? (ml - ep.split_row) : (ml / ep.rs_d1) * ep.rs_m1 + (ml % ep.rs_d2) * ep.rs_m2];
+          }
+      }
+      if (more && tid == 0) pending = atomicAdd(my_ctr, 1);
+      // one wait for all of it; the empty asm statements make the loaded registers "used" here, so that hipcc's own
+      // wait for them lands before the prologue's DMA requests and not (as vmcnt(0)) behind them
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(bcol[0]));
+      asm volatile("" : "+v"(bcol[1]));
+      if constexpr (HAS_SC) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { asm volatile("" : "+v"(sc[p][0])); asm volatile("" : "+v"(sc[p][1])); }
+      }
+      if constexpr (!HAS_PRE) {
+        if (more) { set_tile(t); prologue(); }      // ring is free: the next tile's first 7 regions land under the passes
+      }
+      // The staged rows (and the residual rows) are read back with inline-asm ds_read + lgkmcnt(0) in ONE statement:
+      // hipcc orders any ds_read IT emits behind every LDS-DMA in flight (`s_waitcnt vmcnt(0)`), i.e. pass 0 would
+      // wait for the 14 prologue requests issued just above.
+      typedef __attribute__((address_space(3))) char lds_char;
+      const unsigned stg_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) +
+                                                                    ((lane >> 3) * PP_STG_LD + (lane & 7) * 8) * 4);
+      const unsigned pre_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(pre_lds) + lane * 16);
+#define PP_EPI2(p_, mi_, half_)                                                                         \
+      {                                                                                                 \
+        const int col = lane & 31, rhalf = (lane >> 5) * 4;                                             \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)  \
+            stg[((r & 3) + 8 * (r >> 2) + rhalf) * PP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r] + bcol[ni]; \
+        lgkm0();                                                                                        \
+        __builtin_amdgcn_wave_barrier();                                                                \
+        f32x4 s00, s01, s10, s11;                                                                       \
+        u32x4 pre[2];                                                                                   \
+        if constexpr (HAS_PRE)                                                                          \
+          asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\t"                       \
+                       "ds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %6 offset:2064\n\t"         \
+                       "ds_read_b128 %4, %7 offset:%8\n\tds_read_b128 %5, %7 offset:%9\n\t"             \
+                       "s_waitcnt lgkmcnt(0)"                                                           \
+                       : "=&v"(s00), "=&v"(s01), "=&v"(s10), "=&v"(s11), "=&v"(pre[0]), "=&v"(pre[1])   \
+                       : "v"(stg_rd), "v"(pre_rd), "n"(2 * (p_) * 1024), "n"((2 * (p_) + 1) * 1024) : "memory"); \
+        else                                                                                            \
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"                       \
+                       "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:2064\n\t"         \
+                       "s_waitcnt lgkmcnt(0)"                                                           \
+                       : "=&v"(s00), "=&v"(s01), "=&v"(s10), "=&v"(s11) : "v"(stg_rd) : "memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        float v[2][8];                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+          v[0][j] = s00[j]; v[0][4 + j] = s01[j]; v[1][j] = s10[j]; v[1][4 + j] = s11[j];               \
+        }                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
+          const int m = er + 16 * (p_) + 8 * u;                                                         \
+          const bool ok = col_ok && m < ep.M;                                                           \
+          const bool split = ep.split_row > 0 && m >= ep.split_row;                                     \
+          if (ep.act == 1) {                                                                            \
+            if (ep.C2 && ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, v[u]);  \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] = gelu_erf(v[u][j]);                  \
+          }                                                                                             \
+          if (HAS_PRE && !pre_res) {                                                                    \
+            const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+              v[u][2 * j] *= gelu_erf_grad(__uint_as_float(w[j] << 16));                                \
+              v[u][2 * j + 1] *= gelu_erf_grad(__uint_as_float(w[j] & 0xffff0000u));                    \
+            }                                                                                           \
+          }                                                                                             \
+          if constexpr (HAS_SC) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] *= sc[p_][u]; } \
+          if (HAS_PRE && pre_res && !split) {                                                           \
+            const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+              v[u][2 * j] += __uint_as_float(w[j] << 16);                                               \
+              v[u][2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);                                   \
+            }                                                                                           \
+          }                                                                                             \
+          if (ok) {                                                                                     \
+            if (split) store8(reinterpret_cast<bf16raw*>(ep.Csplit) + (long)(m - ep.split_row) * ep.ldsplit + en, v[u]); \
+            else store8(reinterpret_cast<bf16raw*>(ep.C) + map_row(ep.cmap, m) * ep.ldc + en, v[u]);    \
+          }                                                                                             \
+        }                                                                                               \
+      }
+      PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
+      PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
+#undef PP_EPI2
+      if constexpr (HAS_PRE) {
+        __builtin_amdgcn_s_barrier();               // every wave has read its residual block: the ring may be refilled
+        if (more) { set_tile(t); prologue(); }
+      }
+      if (!more) break;
+    }
   }
   check_out();
 #undef PP_READ_A
@@ -580,40 +732,36 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #undef PP_BAR
 }
 
-static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st) {
+template <bool EPI2, bool HAS_PRE, bool HAS_SC>
+static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st, const Options& cfg) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         PP_LDS_BYTES);
     attr_set = true;
   }
   const int tiles_m = cdiv(d->M, PP_BM), tiles_n = cdiv(d->N, PP_BN);
   // estimated time of one tile in 10-ns ticks of the constant 100 MHz clock (1.5 us per K tile + 6 us)
-  const char* sk = getenv("VTX_GEMM_PP_SKEW");
-  const int tile_ticks = (int)((sk ? atof(sk) : 1.0) * (150 * (d->K / PP_BK) + 600));
+  const int tile_ticks = (int)(cfg.pp_skew * (150 * (d->K / PP_BK) + 600));
   // column tiles per group (tools/gemm_cg.py, M = 100352: 1 is 15 % slower at N = 3072, 3..8 are within noise;
   // K = 3072 wants >= 3): about 6 MB of weight panels, between 3 and 6 tiles
-  const char* cge = getenv("VTX_GEMM_PP_CG");
-  int cg = cge ? atoi(cge) : (int)(6291456L / (512L * d->K));
-  if (!cge && cg < 3) cg = 3;
-  if (!cge && cg > 6) cg = 6;
+  int cg = cfg.pp_cg ? cfg.pp_cg : (int)(6291456L / (512L * d->K));
+  if (!cfg.pp_cg && cg < 3) cg = 3;
+  if (!cfg.pp_cg && cg > 6) cg = 6;
   if (cg < 1) cg = 1;
-  const char* gs = getenv("VTX_GEMM_PP_GRID");
-  const int grid = gs ? atoi(gs) : PP_GRID;
-  // per-XCD tile counters + a check-out counter (9 x 64 B), allocated and zeroed on first use; the kernel
-  // leaves them zeroed.  One set per process: ping-pong GEMMs must not run concurrently on two streams.
-  static int* ctr = nullptr;
-  if (!ctr) {
-    if (hipMalloc(reinterpret_cast<void**>(&ctr), 9 * 64) != hipSuccess || hipMemset(ctr, 0, 9 * 64) != hipSuccess) {
-      ctr = nullptr;
-      set_error("gemm_nt_pp: cannot allocate the tile counters");
-      return VTX_EINVAL;
-    }
-  }
-  hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel, dim3(grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
+  hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
                      (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg,
-                     ctr, ep);
+                     (int*)d->workspace, ep);
   return check_launch("gemm_nt_pp");
+}
+
+static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st) {
+  const Options& cfg = options();
+  if (cfg.pp_epi == 1) return launch_pp_t<false, false, false>(d, ep, st, cfg);
+  // specialised on what the epilogue has to read, so that a plain GEMM carries no prefetch registers
+  const bool pre = d->R || d->dgelu_in, sc = d->row_scale != nullptr;
+  if (pre) return sc ? launch_pp_t<true, true, true>(d, ep, st, cfg) : launch_pp_t<true, true, false>(d, ep, st, cfg);
+  return sc ? launch_pp_t<true, false, true>(d, ep, st, cfg) : launch_pp_t<true, false, false>(d, ep, st, cfg);
 }
 
 // ------------------------------------------------------------------ fp32 kernel
@@ -720,6 +868,8 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_f32_kernel(
 
 using namespace vtx;
 
+extern "C" size_t vtx_gemm_nt_workspace(void) { return 9 * 64; }   // 8 per-XCD tile counters + 1 check-out counter, one 64-B line each
+
 extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   VTX_REQUIRE(d != nullptr, VTX_EINVAL, "gemm_nt: null descriptor");
   VTX_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0, VTX_EINVAL, "gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -731,7 +881,6 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C) && d->lda % vec == 0 && d->ldb % vec == 0 &&
                   d->ldc % vec == 0, VTX_EALIGN, "gemm_nt: operands must be 16-byte aligned");
   VTX_REQUIRE(!d->bias || aligned16(d->bias), VTX_EALIGN, "gemm_nt: bias not aligned");
-  VTX_REQUIRE(!d->bias2 || aligned16(d->bias2), VTX_EALIGN, "gemm_nt: bias2 not aligned");
   VTX_REQUIRE(!d->R || (aligned16(d->R) && d->ldr % vec == 0), VTX_EALIGN, "gemm_nt: residual not aligned");
   VTX_REQUIRE(!(d->act == 1 && d->C2) || (aligned16(d->C2) && d->ldc2 % vec == 0), VTX_EALIGN, "gemm_nt: C2 not aligned");
   VTX_REQUIRE(!d->dgelu_in || (aligned16(d->dgelu_in) && d->ld_dgelu % vec == 0), VTX_EALIGN, "gemm_nt: dgelu_in not aligned");
@@ -748,25 +897,27 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   ep.row_scale = d->row_scale; ep.rs_d1 = d->rs_d1; ep.rs_m1 = d->rs_m1; ep.rs_d2 = d->rs_d2; ep.rs_m2 = d->rs_m2;
   ep.R = d->R; ep.ldr = d->ldr; ep.rmap = d->rmap; ep.r_period = d->r_period;
   ep.split_row = d->split_row; ep.Csplit = d->Csplit; ep.ldsplit = d->ldsplit;
-  ep.bias2 = d->bias2;
 
   const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
   dim3 grid(tiles_m * tiles_n), block(NT_THREADS);
   hipStream_t st = as_stream(stream);
   if (d->dtype == VTX_BF16) {
     const size_t lds = STAGE_BYTES > 4 * BM * BK16 * 2 ? STAGE_BYTES : 4 * BM * BK16 * 2;
-    const char* nodma = getenv("VTX_GEMM_NODMA");
-    const char* kv = getenv("VTX_GEMM_NT");             // tuning override: pp256 | dma2 | ring128x3 | ring128x4k32 | ring256x3 | ring256x3k32 | ring256x4k32
-    const bool dma_ok = d->K % BK16 == 0 && !(nodma && atoi(nodma) != 0);
-    // default (measured, tools/kernel_bench.py): the 256x128 ring with BK=32 -- 72 KB of LDS, two co-resident
-    // workgroups per CU whose prologue / epilogue overlap each other's main loop
-    std::string variant = kv ? kv : (d->M >= 2048 ? "pp256" : d->M >= 1024 ? "ring256x3k32" : "dma2");
-    if (dma_ok && d->K / BK16 >= 2 && variant == "pp256") return launch_pp(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3") return launch_ring<4, 3, 64>(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x3k32") return launch_ring<4, 3, 32>(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring256x4k32") return launch_ring<4, 4, 32>(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring128x3") return launch_ring<2, 3, 64>(d, ep, st);
-    if (dma_ok && d->K / BK16 >= 3 && variant == "ring128x4k32") return launch_ring<2, 4, 32>(d, ep, st);
+    const Options& o = options();
+    const bool dma_ok = d->K % BK16 == 0 && !o.gemm_nodma;
+    // default: the persistent 256x256 ping-pong kernel for the big activations GEMMs; the 256x128 ring (72 KB of
+    // LDS, two co-resident workgroups per CU) for 1024 <= M < 2048; the two-buffer 128x128 kernel below that
+    const int variant = o.gemm_nt != NT_AUTO ? o.gemm_nt : (d->M >= 2048 ? NT_PP256 : d->M >= 1024 ? NT_RING256X3K32 : NT_DMA2);
+    const int nkt = d->K / BK16;
+    // the ping-pong kernel prefetches the residual and the GELU' input into the same registers, and keeps its
+    // tile counters in the caller's workspace
+    const bool pp_ok = dma_ok && nkt >= 2 && !(d->R && d->dgelu_in) && d->workspace && d->ws_bytes >= vtx_gemm_nt_workspace();
+    if (variant == NT_PP256 && pp_ok) return launch_pp(d, ep, st);
+    if (dma_ok && nkt >= 3 && (variant == NT_RING256X3)) return launch_ring<4, 3, 64>(d, ep, st);
+    if (dma_ok && nkt >= 3 && (variant == NT_RING256X3K32 || variant == NT_PP256)) return launch_ring<4, 3, 32>(d, ep, st);
+    if (dma_ok && nkt >= 3 && variant == NT_RING256X4K32) return launch_ring<4, 4, 32>(d, ep, st);
+    if (dma_ok && nkt >= 3 && variant == NT_RING128X3) return launch_ring<2, 3, 64>(d, ep, st);
+    if (dma_ok && nkt >= 3 && variant == NT_RING128X4K32) return launch_ring<2, 4, 32>(d, ep, st);
     if (dma_ok)
       hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel, grid, block, lds, st, d->M, d->N, d->K, (const bf16raw*)d->A, d->lda,
                          d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, ep);

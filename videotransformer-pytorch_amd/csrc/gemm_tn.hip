@@ -967,17 +967,15 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   if (d->dtype == VTX_BF16) {
     const size_t need = (size_t)2 * TN_BKM * TN_LD * 2;
     const size_t lds = STAGE_BYTES > need ? STAGE_BYTES : need;
-    const char* safe_env = getenv("VTX_TN_SAFE");   // diagnostic path, read per call
-    const bool safe = safe_env && atoi(safe_env) != 0;
-    const char* nodma = getenv("VTX_GEMM_NODMA");
-    const char* tnv = getenv("VTX_GEMM_TN");            // tuning override: pp256 | ring | dma2
-    const bool want_ring = !(tnv && std::string(tnv) == "dma2") && d->M >= 1024;   // "pp256" falls back to the ring when ineligible
+    const Options& o = options();
+    const bool safe = o.tn_safe != 0, nodma = o.gemm_nodma != 0;
+    const bool want_ring = o.gemm_tn != TN_DMA2 && d->M >= 1024;   // "pp256" falls back to the ring when ineligible
     // Default is the 256x128 ring (2 workgroups per CU): with the XCD-aware split-major order it is as fast
     // or faster than the 256x256 ping-pong kernel on every weight-gradient shape of the model
     // (tools/gemm_sweep.py 100352: 2304x768 475 vs 513 us, 768x3072 648 vs 666 us, 768x768 202 vs 195 us);
     // both are bound by the CU's L1 miss capacity.  VTX_GEMM_TN=pp256 selects the ping-pong kernel.
-    const bool want_pp = tnv && std::string(tnv) == "pp256" && tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
-    if (!safe && !(nodma && atoi(nodma) != 0) && want_pp) {
+    const bool want_pp = o.gemm_tn == TN_PP256 && tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
+    if (!safe && !nodma && want_pp) {
       const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
       const int s_p = tp_splits(d->M, d->N1, d->N2);
       const int m_per_p = (d->M / s_p) / TP_BK * TP_BK;        // the last split also takes the remainder
@@ -997,7 +995,7 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
                                       d->colsum, w_elems, d->colsum_accumulate);
       }
     }
-    if (!safe && !(nodma && atoi(nodma) != 0) && want_ring) {
+    if (!safe && !nodma && want_ring) {
       const int tiles1r = cdiv(d->N1, 256);
       // one resident round: 2 workgroups per CU x 256 CUs = 512 slots, as full as the workspace allows
       int s_r = 512 / (tiles1r * tiles2);
@@ -1021,7 +1019,7 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
       if (!d->colsum) return launch_reduce_partials(out.slab, s_r, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
       return launch_reduce_partials(out.slab, s_r, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
                                     d->colsum, w_elems, d->colsum_accumulate);
-    } else if (!safe && !(nodma && atoi(nodma) != 0)) {
+    } else if (!safe && !nodma) {
       const size_t need_d = (size_t)4 * TN_BKM * TN_DLD * 2;
       const size_t lds_d = STAGE_BYTES > need_d ? STAGE_BYTES : need_d;
       hipLaunchKernelGGL(gemm_tn_bf16_dma_kernel, grid, block, lds_d, st, d->M, m_per, (const bf16raw*)d->A, d->lda,

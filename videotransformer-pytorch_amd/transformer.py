@@ -14,7 +14,6 @@ classes other than nn.LayerNorm / nn.GELU, FFN num_layers != 2, and the
 (temporal op with cls / spatial op without cls).
 """
 import numpy as np
-import os
 
 import torch
 import torch.nn as nn
@@ -230,11 +229,7 @@ class DividedTemporalAttentionWithPreNorm(_DividedBase):
                                       self.num_heads, None, True)
             return out
         s = _drop_scale(self.layer_drop, b * p, 3, x.device)
-        # VTX_FUSE_PROJ_TFC=1 folds proj and temporal_fc into one GEMM (functions.fused_proj_tfc).  Off by
-        # default: at B = 32 the 768^3 fp32 products it adds to the backward cost more than the two
-        # [M,768]x[768,768] GEMMs it removes (measured 70.3 vs 69.0 ms per step).
-        fn = F_.TimeAttnFn if os.environ.get('VTX_FUSE_PROJ_TFC', '0') == '1' else F_.TimeAttnUnfusedFn
-        return fn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+        return F_.TimeAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                         self.attn.proj.weight, self.attn.proj.bias, self.temporal_fc.weight,
                         self.temporal_fc.bias, t, self.num_heads, s)
 

@@ -9,7 +9,7 @@ model_pretrain.py:203; BASELINE asks for bf16):
 import torch
 
 from . import _lib, ops, functions  # noqa: F401
-from ._lib import VtxError, load  # noqa: F401
+from ._lib import VtxError, load, set_option  # noqa: F401
 from .ops import set_input_normalization  # noqa: F401
 
 _precision = 'auto'

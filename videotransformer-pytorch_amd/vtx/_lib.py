@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ('rs_d1', C.c_int), ('rs_m1', C.c_int), ('rs_d2', C.c_int), ('rs_m2', C.c_int),
         ('R', C.c_void_p), ('ldr', C.c_long), ('rmap', RowMap), ('r_period', C.c_int),
         ('split_row', C.c_int), ('Csplit', C.c_void_p), ('ldsplit', C.c_long),
-        ('bias2', C.c_void_p),
+        ('workspace', C.c_void_p), ('ws_bytes', C.c_size_t),
     ]
 
 
@@ -77,10 +77,12 @@ vp, ci, cl, cf, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 SIGNATURES = {
     'vtx_version': (ci, []),
     'vtx_last_error_string': (C.c_char_p, []),
+    'vtx_set_option': (ci, [C.c_char_p, C.c_char_p]),
     'vtx_layernorm_fwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, vp, cf, vp, cl, RowMap, vp, vp, vp]),
     'vtx_layernorm_bwd_workspace': (sz, [ci, ci]),
     'vtx_layernorm_bwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, vp, vp, vp, vp, cl,
                                vp, vp, vp, sz, vp]),
+    'vtx_gemm_nt_workspace': (sz, []),
     'vtx_gemm_nt': (ci, [C.POINTER(GemmDesc), vp]),
     'vtx_gemm_tn_workspace': (sz, [ci, ci, ci]),
     'vtx_gemm_tn': (ci, [C.POINTER(GemmTnDesc), vp]),
@@ -141,6 +143,13 @@ def check(rc, what=''):
     if rc != 0:
         msg = load().vtx_last_error_string()
         raise VtxError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def set_option(name, value):
+    """Tuning / diagnostic switch of the library (see vtx_set_option in include/vtx.h)."""
+    rc = load().vtx_set_option(str(name).encode(), str(value).encode())
+    if rc != 0:
+        check(rc, f'vtx_set_option({name}={value})')
 
 
 _TRACE = os.environ.get('VTX_TRACE_CALLS', '0') == '1'

@@ -39,43 +39,9 @@ def weights(p, dtype, need_t=None):
 
 
 def clear_weight_cache():
+    """Drop every staged compute-dtype weight copy (call after out-of-band parameter updates that the cache
+    validity check cannot see)."""
     _wcache.clear()
-    _fcache.clear()
-
-
-_fcache = {}
-
-
-def fused_proj_tfc(proj_w, proj_b, tfc_w, dtype, need_t):
-    """The temporal branch applies two Linears back to back with only DropPath (a per-row scalar,
-    which commutes with a linear map) between them (reference transformer.py:263-267):
-        temporal_fc(s * proj(o)) = s * (o Wc^T + bc) + b_tfc,   Wc = W_tfc W_proj,  bc = W_tfc b_proj.
-    One [M,768]x[768,768] GEMM instead of two in forward and in the input gradient, and one weight
-    gradient GEMM instead of two (dWc; dW_tfc and dW_proj follow from it with 768^3 products).
-    Wc and bc are formed in fp32 from the fp32 master weights and cast once per optimizer step;
-    returns (Wc, Wc^T in `dtype`, bc fp32)."""
-    key = (id(proj_w), id(tfc_w), dtype)
-    ver = (proj_w._version, proj_b._version, tfc_w._version)
-    hit = _fcache.get(key)
-    if (hit is not None and hit[0]() is proj_w and hit[1]() is tfc_w and hit[2] == ver
-            and (hit[4] is not None or not need_t)):
-        return hit[3], hit[4], hit[5]
-    D = proj_w.shape[0]
-    wp32, wt32 = proj_w.detach(), tfc_w.detach()
-    _, wpT32 = ops.cast_transpose(wp32, torch.float32, want_c=False, want_t=True)      # [in, out]
-    wc32 = torch.empty(D, D, dtype=torch.float32, device=proj_w.device)
-    ops.gemm_nt(wt32, wpT32, wc32, D, D, D)                                            # Wc[i][j] = sum_k Wt[i][k] Wp[k][j]
-    bp8 = torch.zeros(8, D, dtype=torch.float32, device=proj_w.device)
-    bp8[0].copy_(proj_b.detach())
-    bc8 = torch.empty(D, 8, dtype=torch.float32, device=proj_w.device)
-    ops.gemm_nt(wt32, bp8, bc8, D, 8, D)                                               # column 0 = Wt bp
-    bc = bc8[:, 0].contiguous()
-    wc, wcT = ops.cast_transpose(wc32, dtype, want_c=True, want_t=need_t)
-    if len(_fcache) > 1024:
-        for k in [k for k, v in _fcache.items() if v[0]() is None or v[1]() is None]:
-            del _fcache[k]
-    _fcache[key] = (weakref.ref(proj_w), weakref.ref(tfc_w), ver, wc, wcT, bc)
-    return wc, wcT, bc
 
 
 def _empty(shape, like, dtype=None):
@@ -92,98 +58,7 @@ def _chk(x):
 # ---------------------------------------------------------------------------------
 class TimeAttnFn(torch.autograd.Function):
     """DividedTemporalAttentionWithPreNorm.forward, use_cls_token=False
-    (reference transformer.py:234-282)."""
-
-    @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec):
-        x = _chk(x)
-        B, N1, D = x.shape
-        N = N1 - 1
-        M = B * N
-        hd = D // heads
-        tm = ops.tokmap(N)
-        dtp = x.dtype
-        xn = _empty((M, D), x)
-        mean = _empty((M,), x, torch.float32)
-        rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
-        wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
-        qkv = _empty((M, 3 * D), x)
-        ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
-        o = _empty((M, D), x)
-        S = M // T
-        lse = _empty((S * heads * T,), x, torch.float32)
-        scale = hd ** -0.5
-        ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, T, heads, hd, scale)
-        # proj and temporal_fc fused algebraically (see fused_proj_tfc): out = x + s (o Wc^T + bc) + b_tfc
-        wc, wcT, bc = fused_proj_tfc(proj_w, proj_b, tfc_w, dtp, any(ctx.needs_input_grad))
-        out = torch.empty_like(x)
-        ops.gemm_nt(o, wc, out, M, D, D, cmap=tm, bias=bc, row_scale=scale_vec, rs=(T, 1, 1, 0), bias2=tfc_b,
-                    R=x, rmap=tm)
-        ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse, proj_w, proj_b, tfc_w,
-                              scale_vec if scale_vec is not None else x.new_empty(0),
-                              *[t for t in (wqT, wcT) if t is not None])
-        ctx.cfg = (T, heads, scale_vec is not None)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, ln_w, mean, rstd, xn, qkv, o, lse, proj_w, proj_b, tfc_w, sv, wqT, wcT = ctx.saved_tensors
-        T, heads, has_scale = ctx.cfg
-        sv = sv if has_scale else None
-        dout = _chk(dout)
-        B, N1, D = x.shape
-        N = N1 - 1
-        M = B * N
-        hd = D // heads
-        S = M // T
-        tm = ops.tokmap(N)
-        dtp = x.dtype
-        # fused proj . temporal_fc:  y = s (o Wc^T + bc) + b_tfc
-        #   dWc = (s dout)^T o,  dbc = colsum(s dout),  db_tfc = colsum(dout),  do = (s dout) Wc
-        if sv is not None:
-            g = _empty((M, D), x)
-            ops.row_scale_copy(dout, g, M, D, smap=tm, s=sv, rs=(T, 1, 1, 0))
-            d_wc, d_bc = ops.gemm_tn(g, o, M, D, D, want_colsum=True)
-            d_tfc_b = ops.colsum(dout, M, D, amap=tm)
-            do = _empty((M, D), x)
-            ops.gemm_nt(g, wcT, do, M, D, D)
-        else:
-            d_wc, d_bc = ops.gemm_tn(dout, o, M, D, D, amap=tm, want_colsum=True)
-            d_tfc_b = d_bc
-            do = _empty((M, D), x)
-            ops.gemm_nt(dout, wcT, do, M, D, D, amap=tm)
-        #   Wc = Wt Wp, bc = Wt bp  ->  dWt = dWc Wp^T + dbc bp^T,  dWp = Wt^T dWc,  dbp = Wt^T dbc   (fp32, 768^3)
-        wp32, wt32 = proj_w.detach(), tfc_w.detach()
-        d_tfc_w = torch.empty(D, D, dtype=torch.float32, device=x.device)
-        ops.gemm_nt(d_wc, wp32, d_tfc_w, D, D, D)                       # [i][k] = sum_j dWc[i][j] Wp[k][j]
-        v8 = torch.zeros(2, 8, D, dtype=torch.float32, device=x.device)
-        v8[0, 0].copy_(d_bc)
-        v8[1, 0].copy_(proj_b.detach())
-        ops.gemm_tn(v8[0], v8[1], 8, D, D, out=d_tfc_w, accumulate=True)   # + dbc (x) bp
-        d_proj_w = ops.gemm_tn(wt32, d_wc, D, D, D)                     # [k][j] = sum_i Wt[i][k] dWc[i][j]
-        dbc8 = torch.zeros(D, 8, dtype=torch.float32, device=x.device)
-        dbc8[:, 0].copy_(d_bc)
-        d_proj_b = ops.gemm_tn(wt32, dbc8, D, D, 8)[:, 0].contiguous()  # Wt^T dbc
-        # attention core
-        dqkv = _empty((M, 3 * D), x)
-        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, T, heads, hd, hd ** -0.5)
-        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M, 3 * D, D, want_colsum=True)
-        dxn = _empty((M, D), x)
-        ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
-        # LayerNorm + residual
-        dx = torch.empty_like(x)
-        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
-        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
-        ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None)
-
-
-class TimeAttnUnfusedFn(torch.autograd.Function):
-    """TimeAttnFn with proj and temporal_fc as two separate GEMMs (VTX_FUSE_PROJ_TFC=0): the literal
-    structure of reference transformer.py:234-282, kept for A/B timing and as a numerical cross-check."""
+    (reference transformer.py:234-282): proj and temporal_fc are two GEMMs with DropPath between them."""
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec):

@@ -22,10 +22,19 @@ def dt(t):
 
 
 def need_cuda(*ts):
+    """Every operand must live on the CURRENT HIP device (kernels are launched on its current stream)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError('vtx: the HIP path needs CUDA/HIP tensors (no CPU fallback); '
                                f'got a tensor on {t.device}')
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f'vtx: tensor on {t.device} but the current device is cuda:{cur} '
+                               '(wrap the call in torch.cuda.device(...))')
 
 
 def ptr(t):
@@ -111,9 +120,23 @@ def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dre
 
 
 # ----------------------------------------------------------------------- GEMM
+_nt_ws = {}
+
+
+def _gemm_nt_workspace(device):
+    """Tile counters of the persistent GEMM: one zeroed buffer per (device, stream); the kernel leaves it
+    zeroed, and launches on one stream are ordered, so it is never shared by two launches in flight."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _nt_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(_lib.load().vtx_gemm_nt_workspace() // 4, dtype=torch.int32, device=device)
+        _nt_ws[key] = ws
+    return ws
+
+
 def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=IDENT, bias=None, act=0,
             C2=None, dgelu_in=None, row_scale=None, rs=(1, 0, 1, 0), R=None, ldr=None, rmap=IDENT,
-            r_period=0, split_row=0, Csplit=None, bias2=None):
+            r_period=0, split_row=0, Csplit=None):
     """C = epilogue(A[M,K] @ B[N,K]^T); see vtx_gemm_nt in include/vtx.h."""
     need_cuda(A, B, Cout)
     if A.dtype != B.dtype or A.dtype != Cout.dtype:
@@ -129,8 +152,8 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
     d.row_scale = ptr(_f32(row_scale)); d.rs_d1, d.rs_m1, d.rs_d2, d.rs_m2 = [int(v) for v in rs]
     d.R = ptr(R); d.ldr = (N if ldr is None else ldr); d.rmap = rmap; d.r_period = int(r_period)
     d.split_row = int(split_row); d.Csplit = ptr(Csplit); d.ldsplit = N
-    b2 = _f32(bias2)
-    d.bias2 = ptr(b2)
+    ws = _gemm_nt_workspace(A.device)
+    d.workspace = ptr(ws); d.ws_bytes = ws.numel() * 4
     if _lib._TRACE:
         import sys
         sys.stderr.write(f'[vtx]   gemm_nt M={M} N={N} K={K} lda={d.lda} ldc={d.ldc} A={tuple(A.shape)} B={tuple(B.shape)} C={tuple(Cout.shape)} amap=({amap.grp},{amap.skip},{amap.base}) cmap=({cmap.grp},{cmap.skip},{cmap.base}) bias={bias is not None} rs={row_scale is not None} R={R is not None} split={split_row}\n')
