@@ -6,16 +6,25 @@ all-reduce for N > 1) + SGD update, on N GPUs of one node (one process per GPU, 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the keys below).  `value` = clips/s over all N GPUs
-with clips already resident in HBM.  `roofline` is for the dominant kernel
-(gemm_nt_bf16_kernel): achieved = algorithmic FLOPs (2*M*N*K per launch) / launch time
-measured with HIP events on the launch stream inside the timed region, against the
-2.5 PFLOP/s dense bf16 MFMA peak.  `cpu_baseline` times the CPU oracle (oracle/, fp32,
-all host cores) on a bounded sample of the same workload -- a reported baseline only.
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
+torch.distributed.run with N ranks (one per GPU, rendezvous on 127.0.0.1); if the node has fewer
+than N GPUs it says so on stderr and runs on the GPUs that exist (`n_gpus` reports the real count).
+
+Prints ONE JSON line on rank 0.  `value` = clips/s over all N GPUs with clips already resident in
+HBM.  `roofline` is for the dominant kernel class (all vtx_gemm_nt launches): achieved =
+algorithmic FLOPs (2*M*N*K per launch) / launch time measured with HIP events on the launch stream
+inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak.  After the timed region a
+short instrumented pass (not part of `value`) times every kernel class the same way:
+`gemm_shapes` (each GEMM shape of the step with its own algorithmic bytes, bound and fraction of
+that bound) and `roofline_hbm` (LayerNorm, attention cores, patch gather, HOG against 8 TB/s).
+`cpu_baseline` times the CPU oracle (oracle/, fp32, the host cores this process may use) on a
+bounded sample of the same workload -- a reported baseline only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +38,7 @@ import torch.distributed as dist  # noqa: E402
 
 FLOPS_FWD_BWD_PER_CLIP = {8: 1.175e12, 16: 2.352e12, 2: 0.2937e12}
 PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
+PEAK_HBM = 8.0         # TB/s (spec; ~6.3 TB/s is what a streaming copy reaches)
 
 
 def parse():
@@ -36,12 +46,14 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='clips per GPU (weak scaling)')
+    ap.add_argument('--batch', type=int, default=96, help='clips per GPU (weak scaling)')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--breakdown', action='store_true', help='extra instrumented pass: per-kernel-class time')
+    ap.add_argument('--no-breakdown', action='store_true', help='skip the instrumented per-kernel-class pass')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--optimizer', default='fused', choices=['fused', 'torch'],
+                    help='fused = vtx multi-tensor SGD-nesterov kernel; torch = torch.optim.SGD (foreach)')
     return ap.parse_args()
 
 
@@ -63,7 +75,6 @@ def _host_cores():
 def cpu_baseline_subprocess(frames, budget_s=150):
     """Run cpu_baseline() in a child process with a hard wall-clock bound so that the default
     bench run always finishes within minutes, whatever the GPU box's host looks like."""
-    import subprocess
     code = ('import sys, json; sys.path.insert(0, %r); import bench; '
             'print("CPU_BASELINE " + json.dumps(bench.cpu_baseline(%d)))' % (ROOT, frames))
     try:
@@ -78,9 +89,10 @@ def cpu_baseline_subprocess(frames, budget_s=150):
             'sample': 'oracle/vt_oracle.py TimeSformer-B fwd+bwd, batch 1: ' + why}
 
 
-def cpu_baseline(frames, steps=1):
+def cpu_baseline(frames, steps=3, budget_s=60.0):
     """CPU oracle (fp32, torch CPU kernels on the host cores this process may use, at most 32),
-    train-mode fwd+bwd of the same model on one clip: 1 warm-up + `steps` timed."""
+    train-mode fwd+bwd of the same model on one clip: 1 warm-up + `steps` timed (SURVEY.md 8(d) asks
+    for >= 3; fewer only if they would exceed `budget_s` seconds, and the count is reported)."""
     from oracle import synth, vt_oracle as O
     import video_transformer as V
     torch.set_num_threads(min(_host_cores(), 32))
@@ -89,6 +101,7 @@ def cpu_baseline(frames, steps=1):
         v.requires_grad_(True)
     x = synth.synth_clip(1, frames, seed=1)
     times = []
+    t_begin = time.perf_counter()
     for i in range(steps + 1):
         for v in sd.values():
             v.grad = None
@@ -97,39 +110,93 @@ def cpu_baseline(frames, steps=1):
         y = O.timesformer_forward(sd, x, frames, training=True)
         y.sum().backward()
         times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / steps
+        if len(times) >= 2 and time.perf_counter() - t_begin + times[-1] > budget_s:
+            break
+    timed = times[1:]
+    t = sum(timed) / len(timed)
     return {'value': round(1.0 / t, 4), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'oracle/vt_oracle.py TimeSformer-B {frames}x224^2 fp32 train fwd+bwd, batch 1, '
-                      f'{steps} timed steps after 1 warm-up'}
-
+                      f'{len(timed)} timed steps after 1 warm-up ({sum(timed):.1f} s of CPU work)'}
 
 
 def pmc_traffic_per_launch(B, args):
     """HBM-side bytes per vtx_gemm_nt launch from the committed rocprofv3 PMC passes of THIS command
-    (profiles/round1_pmc_{FETCH,WRITE}_SIZE_b64.txt: separate --pmc passes, KB per dispatch summed over
+    (profiles/round2_pmc_{FETCH,WRITE}_SIZE_b<B>.txt: separate --pmc passes, KB per dispatch summed over
     the listed dispatches).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced
-    streams on gfx950; WRITE_SIZE is uncalibrated and taken as is.  None when the configuration differs
-    from the profiled one (the counters cannot be collected from inside the timed run)."""
-    if B != 64 or args.precision != 'bf16' or args.frames != 8:
+    streams on gfx950; WRITE_SIZE is uncalibrated and taken as is.  None when no committed pass matches
+    the configuration (the counters cannot be collected from inside the timed run)."""
+    if args.precision != 'bf16' or args.frames != 8:
         return None
     here = os.path.dirname(os.path.abspath(__file__))
     tot = 0.0
-    for name, mult in (('round1_pmc_FETCH_SIZE_b64.txt', 2.0), ('round1_pmc_WRITE_SIZE_b64.txt', 1.0)):
+    for name, mult in ((f'round2_pmc_FETCH_SIZE_b{B}.txt', 2.0), (f'round2_pmc_WRITE_SIZE_b{B}.txt', 1.0)):
         try:
+            got = False
             for line in open(os.path.join(here, 'profiles', name)):
                 if 'gemm_nt_bf16_pp_kernel' in line:
                     f = dict(kv.split('=') for kv in line.split() if '=' in kv)
                     tot += mult * float(f['total']) * 1024.0 / float(f['rows'])
+                    got = True
+            if not got:
+                return None
         except (OSError, KeyError, ValueError):
             return None
     return round(tot, 0) if tot > 0 else None
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script on 127.0.0.1."""
+    have = torch.cuda.device_count()
+    n = args.gpus
+    if have < n:
+        sys.stderr.write(f'bench.py: --gpus {n} requested but this node has {have} GPU(s); running on {max(have, 1)}\n')
+        n = max(have, 1)
+    if n <= 1:
+        return False
+    argv = [a for a in sys.argv[1:]]
+    for i, a in enumerate(argv):                      # the ranks get the real count
+        if a == '--gpus':
+            argv[i + 1] = str(n)
+        elif a.startswith('--gpus='):
+            argv[i] = f'--gpus={n}'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    rc = subprocess.run(cmd, env=env).returncode
+    sys.exit(rc)
+
+
+def gemm_shape_table(per_shape, peak_tf):
+    """[{shape, launches_per_step, avg_us, tflops, alg_mb, tb_per_s, bound, frac}] from ops.profile_stop() entries."""
+    rows = []
+    for key, (n, ms, fl, by) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
+        t = ms * 1e-3 / n
+        t_m, t_h = fl / n / (peak_tf * 1e12), by / n / (PEAK_HBM * 1e12)
+        rows.append({'shape': key, 'launches': n, 'avg_us': round(t * 1e6, 1), 'tflops': round(fl / n / t / 1e12, 1),
+                     'alg_mb': round(by / n / 1e6, 1), 'tb_per_s': round(by / n / t / 1e12, 2),
+                     'bound': 'mfma' if t_m >= t_h else 'hbm', 'frac': round(max(t_m, t_h) / t, 3)})
+    return rows
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn_under_torchrun(args)                  # does not return when it spawned the ranks
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}\n')
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    assert local < torch.cuda.device_count(), f'rank {rank}: no GPU {local} on this node'
     # host threads: never more than the cgroup CPU quota allows (an oversubscribed ATen pool gets the
     # whole process CFS-throttled, which shows up as ~90 ms launch stalls)
     torch.set_num_threads(max(1, min(_host_cores() // max(world, 1), 16)))
@@ -143,7 +210,7 @@ def main():
     import __graft_entry__ as ge
     ge.ensure_built()
     import vtx
-    from vtx import dp, ops
+    from vtx import dp, ops, optim
     import transformer as T
     import video_transformer as V
 
@@ -159,8 +226,15 @@ def main():
     params = list(model.parameters()) + list(head.parameters())
     dp.broadcast_parameters(model)
     dp.broadcast_parameters(head)
-    buckets = dp.GradBuckets(params, force_comm=force_dp) if (world > 1 or force_dp) else None
-    opt = None if args.no_optimizer else torch.optim.SGD(params, lr=1e-4, momentum=0.9, nesterov=True)
+    # gradients live in flat per-layer buckets: the all-reduce units for N > 1 and the multi-tensor
+    # optimizer's operands for any N
+    buckets = dp.GradBuckets(params, force_comm=force_dp)
+    opt = None
+    if not args.no_optimizer:
+        if args.optimizer == 'fused':
+            opt = optim.FusedSGD(buckets, lr=1e-4, momentum=0.9, nesterov=True)
+        else:
+            opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, nesterov=True)
 
     B = args.batch
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
@@ -168,16 +242,11 @@ def main():
     labels = torch.randint(0, 400, (B,), generator=g).to(dev)
 
     def step():
-        if buckets is not None:
-            buckets.zero()
-        else:
-            for p in params:
-                p.grad = None
+        buckets.zero()
         logits = head(model(x))
         loss = torch.nn.functional.cross_entropy(logits, labels)
         loss.backward()
-        if buckets is not None:
-            buckets.finish()
+        buckets.finish()
         if opt is not None:
             opt.step()
         return loss
@@ -203,26 +272,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.detach())
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
 
-    breakdown = None
-    if args.breakdown and rank == 0:
-        classes = ('gemm_nt', 'gemm_tn', 'attn_fwd', 'attn_bwd', 'ln_fwd', 'ln_bwd', 'colsum')
-        ops.profile_start(classes)
+    # ---- instrumented pass (outside the timed region): every kernel class, HIP events per launch ----
+    classes = None
+    if not args.no_breakdown and rank == 0:
+        names = ('gemm_nt', 'gemm_tn', 'attn_fwd_time', 'attn_bwd_time', 'attn_fwd_space', 'attn_bwd_space', 'ln_fwd', 'ln_bwd',
+                 'colsum', 'patch_rows', 'hog')
+        nb = 2
+        ops.profile_start(names)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(nb):
             step()
         torch.cuda.synchronize()
-        tot = (time.perf_counter() - t1) / 3 * 1e3
-        pr = ops.profile_stop()
-        breakdown = {c: {'launches_per_step': n // 3, 'ms_per_step': round(ms / 3, 3),
-                         'work_per_s': round(w / (ms * 1e-3), 3) if ms else None} for c, (n, ms, w) in pr.items()}
-        breakdown['step_ms_instrumented'] = round(tot, 3)
+        step_ms = (time.perf_counter() - t1) / nb * 1e3
+        frames_u8 = torch.randint(0, 256, (64, 224, 224, 3), dtype=torch.uint8, device=dev)   # MaskFeat HOG targets
+        for _ in range(nb):
+            ops.hog_fwd(frames_u8)
+        torch.cuda.synchronize()
+        classes = ops.profile_stop()
+        classes['_step_ms'] = step_ms
+        classes['_steps'] = nb
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
+        peak = PEAK_BF16 if args.precision == 'bf16' else 157.3
         clips = world * B * args.steps
         value = clips / elapsed
-        n, ms, flops = prof['gemm_nt']
+        n, ms, flops, nbytes = ops.profile_totals(prof)['gemm_nt']
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out = {
             'metric': 'clips/sec TimeSformer-B divided_space_time %dx3x224x224 fwd+bwd (whole job)' % args.frames,
@@ -231,23 +310,45 @@ def main():
             'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': 'TimeSformer-B divided_space_time, %d frames x 3x224x224, %s, fwd+CE+bwd%s, '
                                    'random-init weights' % (args.frames, args.precision,
-                                                            '' if args.no_optimizer else '+SGD(nesterov)'),
+                                                            '' if args.no_optimizer else '+SGD(nesterov, %s)' % args.optimizer),
                        'clips_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'grad_exchange': 'RCCL all-reduce, per-layer fp32 buckets overlapped with backward'
-                       if world > 1 else 'none'},
+                       'grad_exchange': 'RCCL all-reduce (world size %d), per-layer fp32 buckets overlapped with backward' % rccl_world
+                       if (world > 1 or force_dp) else 'none'},
             'clips_per_sec_per_gpu': round(value / world, 3),
             'model_tflops_per_gpu': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12, 2),
             'mfma_frac_whole_step': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12 / PEAK_BF16, 4),
             'final_loss': round(final_loss, 4),
             'roofline': {'kernel': 'gemm_nt_bf16_pp_kernel (all vtx_gemm_nt launches)' if args.precision == 'bf16' else 'gemm_nt_f32_kernel',
-                         'bound': 'mfma', 'achieved': round(achieved, 2),
-                         'peak': PEAK_BF16 if args.precision == 'bf16' else 157.3, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / (PEAK_BF16 if args.precision == 'bf16' else 157.3), 4),
+                         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4),
                          'traffic': pmc_traffic_per_launch(B, args), 'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
-                         'flops_per_launch_avg': round(flops / max(n, 1), 0)},
+                         'flops_per_launch_avg': round(flops / max(n, 1), 0),
+                         'algorithmic_bytes_per_launch_avg': round(nbytes / max(n, 1), 0)},
         }
-        if breakdown is not None:
-            out['breakdown'] = breakdown
+        if classes is not None:
+            nb = classes.pop('_steps')
+            out['instrumented_step_ms'] = round(classes.pop('_step_ms'), 3)
+            tot = ops.profile_totals(classes)
+            out['gemm_shapes'] = {'nt': gemm_shape_table(classes['gemm_nt'], peak), 'tn': gemm_shape_table(classes['gemm_tn'], peak)}
+            for k in ('nt', 'tn'):
+                for r in out['gemm_shapes'][k]:
+                    r['launches_per_step'] = r.pop('launches') // nb
+            out['gemm_tn_roofline'] = {'achieved': round(tot['gemm_tn'][2] / (tot['gemm_tn'][1] * 1e-3) / 1e12, 2), 'peak': peak,
+                                       'unit': 'TFLOP/s', 'frac': round(tot['gemm_tn'][2] / (tot['gemm_tn'][1] * 1e-3) / 1e12 / peak, 4),
+                                       'ms_per_step': round(tot['gemm_tn'][1] / nb, 3)}
+            hbm = []
+            label = {'ln_fwd': 'ln_fwd_kernel', 'ln_bwd': 'ln_bwd_kernel', 'attn_fwd_time': 'attn_fwd_small_kernel (temporal, T tokens)',
+                     'attn_bwd_time': 'attn_bwd_small_kernel (temporal)', 'attn_fwd_space': 'attn_fwd_mfma_kernel (spatial, 197 tokens)',
+                     'attn_bwd_space': 'attn_bwd_*_mfma_kernel (spatial)', 'patch_rows': 'patch_rows_kernel (clip gather)',
+                     'colsum': 'colsum_kernel', 'hog': 'hog_kernel (64 frames 224x224x3 uint8 -> float64 features)'}
+            for c, (cn, cms, cfl, cby) in tot.items():
+                if c in label and cn:
+                    a = cby / (cms * 1e-3) / 1e12
+                    per_step = None if c == 'hog' else round(cms / nb, 3)
+                    hbm.append({'kernel': label[c], 'bound': 'hbm', 'achieved': round(a, 3), 'peak': PEAK_HBM, 'unit': 'TB/s',
+                                'frac': round(a / PEAK_HBM, 4), 'avg_launch_us': round(cms / cn * 1e3, 1),
+                                'algorithmic_mb_per_launch': round(cby / cn / 1e6, 2), 'ms_per_step': per_step})
+            out['roofline_hbm'] = hbm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_subprocess(args.frames)
     else:

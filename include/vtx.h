@@ -250,6 +250,33 @@ int vtx_maskfeat_loss_bwd(int dtype, int B, int Tq, int ts, int g, int Cf, const
                           const double* target, const uint8_t* cmask, const double* loss_out,
                           float gloss, void* dpred, long lddp, void* stream);
 
+/* ------------------------------------------------- optimizer step / gradient clipping
+ * The step right after backward (model_trainer.py:155-170 clip_gradients, :218-231; optimizer.py:31-38):
+ * every parameter is one row of a DEVICE table; three launches per step whatever the parameter count.
+ * chunk_start: device int[n_tensors + 1], exclusive prefix sum of vtx_mt_chunks(numel) per tensor;
+ * n_chunks = chunk_start[n_tensors].  All tensors fp32, contiguous. */
+typedef struct {
+  void* p;         /* parameter                                   */
+  const void* g;   /* gradient                                    */
+  void* s1;        /* SGD momentum buffer / AdamW exp_avg         */
+  void* s2;        /* AdamW exp_avg_sq (NULL for SGD)             */
+  long n;          /* elements                                    */
+  float lr, wd;    /* learning rate and weight decay of its group */
+} vtx_mt_tensor;
+int vtx_mt_chunks(long numel);
+/* norms[t] = ||g_t||_2 (t < n_tensors), norms[n_tensors] = ||(norms[0..n))||_2 -- the value the reference's
+ * clip_gradients returns.  partial: float[n_chunks] scratch.  Deterministic (fixed summation order). */
+int vtx_mt_grad_norms(const vtx_mt_tensor* tab, const int* chunk_start, int n_tensors, int n_chunks,
+                      float* partial, float* norms, void* stream);
+/* torch.optim.SGD(momentum, nesterov, dampening 0, weight_decay = tab[t].wd): g += wd p; buf = first_step ? g :
+ * momentum buf + g; p -= lr (nesterov ? g + momentum buf : buf).  clip > 0: g is first scaled by
+ * min(1, clip / (norms[t] + 1e-6)) (per parameter, model_trainer.py:165-168); the stored gradient is not modified. */
+int vtx_mt_sgd_step(const vtx_mt_tensor* tab, const int* chunk_start, int n_tensors, int n_chunks, const float* norms,
+                    float clip, float momentum, int nesterov, int first_step, void* stream);
+/* torch.optim.AdamW(betas, eps, weight_decay = tab[t].wd), step counted from 1. */
+int vtx_mt_adamw_step(const vtx_mt_tensor* tab, const int* chunk_start, int n_tensors, int n_chunks, const float* norms,
+                      float clip, float beta1, float beta2, float eps, int step, void* stream);
+
 /* MFMA / LDS-transpose layout self-test: runs one-hot probes through the
  * instructions the GEMM kernels rely on and writes a report; returns the
  * number of layout assumptions that failed (0 = all hold). */

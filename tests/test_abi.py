@@ -62,7 +62,7 @@ def test_struct_layouts_match_ctypes(tmp_path):
     import subprocess
     from vtx import _lib
     structs = {'vtx_rowmap': _lib.RowMap, 'vtx_gemm_desc': _lib.GemmDesc, 'vtx_gemm_tn_desc': _lib.GemmTnDesc,
-               'vtx_attn_desc': _lib.AttnDesc, 'vtx_attn_bwd_desc': _lib.AttnBwdDesc}
+               'vtx_attn_desc': _lib.AttnDesc, 'vtx_attn_bwd_desc': _lib.AttnBwdDesc, 'vtx_mt_tensor': _lib.MtTensor}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "vtx.h")}"',
              'int main(void) {']
     for cname, cls in structs.items():
@@ -86,7 +86,9 @@ def test_struct_layouts_match_ctypes(tmp_path):
 
 
 def test_bench_traffic_helper_reads_committed_pmc_passes():
-    """bench.py derives roofline.traffic from the committed rocprofv3 PMC dumps of the default command."""
+    """bench.py derives roofline.traffic from the committed rocprofv3 PMC dumps of the default command
+    (profiles/round2_pmc_{FETCH,WRITE}_SIZE_b<batch>.txt); any other configuration has no counters."""
+    import glob
     import importlib.util
     import sys
     spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
@@ -94,14 +96,19 @@ def test_bench_traffic_helper_reads_committed_pmc_passes():
     argv, sys.argv = sys.argv, ['bench.py']
     try:
         spec.loader.exec_module(mod)
+        default_batch = mod.parse().batch
     finally:
         sys.argv = argv
 
     class A:
         precision, frames = 'bf16', 8
-    t = mod.pmc_traffic_per_launch(64, A)
-    assert t is not None and 2e8 < t < 5e9, t            # a few hundred MB .. a few GB per GEMM launch
-    assert mod.pmc_traffic_per_launch(32, A) is None     # only the profiled configuration has counters
+    committed = glob.glob(os.path.join(ROOT, 'profiles', f'round2_pmc_FETCH_SIZE_b{default_batch}.txt'))
+    t = mod.pmc_traffic_per_launch(default_batch, A)
+    if committed:
+        assert t is not None and 2e8 < t < 5e9, t        # a few hundred MB .. a few GB per GEMM launch
+    else:
+        assert t is None
+    assert mod.pmc_traffic_per_launch(7, A) is None      # only the profiled configuration has counters
 
 
 def test_options_api():

@@ -1,0 +1,91 @@
+"""Multi-tensor optimizer step and per-parameter gradient norms / clipping (csrc/optim.hip) against
+torch.optim and the reference's clip_gradients arithmetic (model_trainer.py:155-170)."""
+import pytest
+import torch
+
+from helpers import check
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SHAPES = [(768, 768), (3,), (4097,), (2304, 768), (1, 1, 768), (5, 7, 11), (8192,), (12288 + 4,)]
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(*s, generator=g) for s in SHAPES]
+
+
+def _reference_clip(grads, clip):
+    """model_trainer.py:155-170 on CPU doubles -> (clipped grads, total norm)."""
+    norms, out = [], []
+    for g in grads:
+        n = g.double().norm(2)
+        norms.append(n)
+        c = clip / (n + 1e-6) if clip else 1.0
+        out.append(g.double() * c if (clip and c < 1) else g.double())
+    return out, torch.stack(norms).norm(2)
+
+
+@pytest.mark.parametrize('clip', [None, 0.5])
+@pytest.mark.parametrize('kind', ['sgd', 'adamw'])
+def test_fused_step_matches_torch(kind, clip):
+    from vtx import optim
+    init = _params(1)
+    p_ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    p_gpu = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    groups = lambda ps: [{'params': ps[:3], 'weight_decay': 0.0}, {'params': ps[3:]}]   # noqa: E731
+    if kind == 'sgd':
+        o_ref = torch.optim.SGD(groups(p_ref), lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.05)
+        o_gpu = optim.FusedSGD(groups(p_gpu), lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.05, clip_grad=clip)
+    else:
+        o_ref = torch.optim.AdamW(groups(p_ref), lr=0.01, betas=(0.9, 0.999), weight_decay=0.05)
+        o_gpu = optim.FusedAdamW(groups(p_gpu), lr=0.01, betas=(0.9, 0.999), weight_decay=0.05, clip_grad=clip)
+    for step in range(4):
+        grads = [g * (0.3 if i % 2 else 3.0) for i, g in enumerate(_params(10 + step))]
+        clipped, total = _reference_clip(grads, clip)
+        for pr, pg, g, gc in zip(p_ref, p_gpu, grads, clipped):
+            pr.grad = gc.clone()
+            pg.grad = g.clone().to(DEV)
+        if step == 2:                                   # a scheduler rewrites the decayed group between steps
+            o_ref.param_groups[1]['weight_decay'] = 0.02
+            o_gpu.param_groups[1]['weight_decay'] = 0.02
+            o_ref.param_groups[0]['lr'] *= 0.5
+            o_gpu.param_groups[0]['lr'] *= 0.5
+        v0 = p_gpu[0]._version
+        o_ref.step()
+        o_gpu.step()
+        assert p_gpu[0]._version > v0, 'the in-place kernel update must bump the version counter (weight cache)'
+        if clip:
+            check(f'{kind} total grad norm step {step}', o_gpu.last_grad_norm.cpu(), total, 1e-5)
+        for i, (pr, pg) in enumerate(zip(p_ref, p_gpu)):
+            check(f'{kind} clip={clip} step {step} param {i}', pg.detach().cpu(), pr.detach(), 2e-6)
+
+
+def test_grad_norm_is_the_reference_statistic():
+    from vtx import optim
+    ps = [torch.nn.Parameter(t.to(DEV)) for t in _params(3)]
+    grads = _params(4)
+    for p, g in zip(ps, grads):
+        p.grad = g.to(DEV)
+    o = optim.FusedSGD(ps, lr=0.1)
+    _, total = _reference_clip(grads, None)
+    check('grad_norm', o.grad_norm().cpu(), total, 1e-6)
+    n1 = o.grad_norm().clone()
+    assert torch.equal(n1, o.grad_norm()), 'norms are deterministic (fixed summation order)'
+
+
+def test_build_optimizer_groups_like_the_reference():
+    """optimizer.build_optimizer: no-decay group first (1-D, biases, pos_embed / cls_token), then the decayed one."""
+    import types
+    import optimizer
+    import video_transformer as V
+    m = V.TimeSformer(num_frames=2, img_size=32, patch_size=16, embed_dims=64, num_heads=1, num_transformer_layers=1).to(DEV)
+    hp = types.SimpleNamespace(optim_type='adamw', lr=1e-3, weight_decay=0.05, arch='timesformer', layer_decay=1)
+    opt = optimizer.build_optimizer(hp, m, is_pretrain=False)
+    names = {id(p): n for n, p in m.named_parameters()}
+    g0 = {names[id(p)] for p in opt.param_groups[0]['params']}
+    g1 = {names[id(p)] for p in opt.param_groups[1]['params']}
+    assert opt.param_groups[0]['weight_decay'] == 0 and opt.param_groups[1]['weight_decay'] == 0.05
+    assert {'pos_embed', 'cls_token', 'time_embed', 'norm.weight', 'patch_embed.projection.bias'} <= g0
+    assert 'patch_embed.projection.weight' in g1 and all(n.endswith('weight') for n in g1)
+    assert len(g0) + len(g1) == len(names)

@@ -47,6 +47,7 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }
   if (strcmp(name, "pp_epi") == 0) { o.pp_epi = atoi(value); return VTX_OK; }
   if (strcmp(name, "pp_skew") == 0) { o.pp_skew = (float)atof(value); return VTX_OK; }
+  if (strcmp(name, "pp_trace") == 0) { o.pp_trace = strtoull(value, nullptr, 0); return VTX_OK; }
   return VTX_EINVAL;
 }
 

@@ -374,7 +374,7 @@ template <bool EPI2, bool HAS_PRE, bool HAS_SC>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, int* __restrict__ tile_ctr,
-    EpiParams ep) {
+    long long* __restrict__ trace, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -382,6 +382,12 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   const int wr = wave >> 2, wc = wave & 3;
   float* stg = reinterpret_cast<float*>(smem + PP_RING_BYTES) + wave * 16 * PP_STG_LD;
   const int nk = K / PP_BK;
+  // timeline of the first 8 tiles of every workgroup (tools/pp_timeline.py): 100 MHz ticks at 8 points per tile
+  int trace_tile = 0;
+  auto stamp = [&](int e) {
+    if (trace != nullptr && tid == 0 && trace_tile < 8)
+      trace[((long)blockIdx.x * 8 + trace_tile) * 8 + e] = (long long)__builtin_amdgcn_s_memrealtime();
+  };
 
   // Tile walk.  XCD x owns the row tiles [rlo, rhi) for ALL column tiles and walks them column-group
   // major: CG column tiles at a time over all its row tiles, so the 32 workgroups of an XCD work on
@@ -523,8 +529,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     bf16x8 fa[2][4], fb0[4], fb1[4];
     // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
     // younger request in flight (2 DMA instructions per region; issue order A0 B0 B1 A1 per K tile).
+    stamp(0);
     wait_vmcnt<10>();                             // A0(0), B0(0) landed; B1(0) A1(0) A0(1) B0(1) B1(1) in flight
     PP_BAR();
+    stamp(1);
     if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
@@ -559,6 +567,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       PP_BAR();
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
+    stamp(2);
     const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
     if constexpr (!EPI2) {
       t = next_tile();
@@ -585,6 +594,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // not an atomic round trip; the draw for the tile after it goes out below and returns under the
       // epilogue's own load latency.
       t = publish(pending);
+      stamp(3);
       const bool more = t < tend;
       // Every global READ of the epilogue happens HERE, before the tile's first store.  vmcnt counts loads and
       // stores together and a wait can only name "all but the N youngest": a load waited for inside the store
@@ -644,6 +654,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // one wait for all of it; the empty asm statements make the loaded registers "used" here, so that hipcc's own
       // wait for them lands before the prologue's DMA requests and not (as vmcnt(0)) behind them
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(4);
       asm volatile("" : "+v"(bcol[0]));
       asm volatile("" : "+v"(bcol[1]));
       if constexpr (HAS_SC) {
@@ -653,6 +664,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       if constexpr (!HAS_PRE) {
         if (more) { set_tile(t); prologue(); }      // ring is free: the next tile's first 7 regions land under the passes
       }
+      stamp(5);
       // The staged rows (and the residual rows) are read back with inline-asm ds_read + lgkmcnt(0) in ONE statement:
       // hipcc orders any ds_read IT emits behind every LDS-DMA in flight (`s_waitcnt vmcnt(0)`), i.e. pass 0 would
       // wait for the 14 prologue requests issued just above.
@@ -718,10 +730,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
       PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
 #undef PP_EPI2
+      stamp(6);
       if constexpr (HAS_PRE) {
         __builtin_amdgcn_s_barrier();               // every wave has read its residual block: the ring may be refilled
         if (more) { set_tile(t); prologue(); }
       }
+      stamp(7);
+      ++trace_tile;
       if (!more) break;
     }
   }
@@ -751,7 +766,7 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   if (cg < 1) cg = 1;
   hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
                      (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg,
-                     (int*)d->workspace, ep);
+                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, ep);
   return check_launch("gemm_nt_pp");
 }
 

@@ -40,6 +40,15 @@ def _to_compute(x):
     return F_.CastFn.apply(x, vtx.compute_dtype())
 
 
+def _build_norm(norm_layer, embed_dims):
+    """norm_layer is nn.LayerNorm or a callable producing one (e.g. functools.partial(nn.LayerNorm, eps=1e-6),
+    the timm idiom); anything else has no HIP kernel."""
+    norm = norm_layer(embed_dims)
+    if type(norm) is not nn.LayerNorm or not norm.elementwise_affine or tuple(norm.normalized_shape) != (embed_dims,):
+        raise NotImplementedError('vtx: only nn.LayerNorm (elementwise affine, over embed_dims) is supported as norm_layer')
+    return norm
+
+
 def _no_dropout(p, what):
     if p:
         raise NotImplementedError(f'vtx: {what} > 0 is not supported by the HIP path '
@@ -178,13 +187,11 @@ class _DividedBase(nn.Module):
     def __init__(self, embed_dims, num_heads, num_frames, use_cls_token, attn_drop, proj_drop, layer_drop,
                  norm_layer):
         super().__init__()
-        if norm_layer is not nn.LayerNorm:
-            raise NotImplementedError('vtx: only nn.LayerNorm is supported as norm_layer')
         self.embed_dims = embed_dims
         self.num_heads = num_heads
         self.num_frames = num_frames
         self.use_cls_token = use_cls_token
-        self.norm = norm_layer(embed_dims)
+        self.norm = _build_norm(norm_layer, embed_dims)
         self.attn = Attention(embed_dims, num_heads, qkv_bias=True, attn_drop=attn_drop)
         self.proj_drop = nn.Dropout(proj_drop)
         self.layer_drop = _build_layer_drop(layer_drop)
@@ -221,17 +228,19 @@ class DividedTemporalAttentionWithPreNorm(_DividedBase):
         x = _to_compute(query)
         b, n1, d = x.shape
         t = self.num_frames
+        if (n1 - 1) % t:
+            raise ValueError(f'{n1 - 1} tokens per clip are not a multiple of num_frames={t}')
         p = (n1 - 1) // t
         if return_attention:
             tok = x[:, 1:].reshape(b * p, t, d)
             out = F_.SelfAttnFn.apply(tok, self.norm.weight, self.norm.bias, self.attn.qkv.weight,
                                       self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias,
-                                      self.num_heads, None, True)
+                                      self.num_heads, None, True, self.norm.eps)
             return out
         s = _drop_scale(self.layer_drop, b * p, 3, x.device)
         return F_.TimeAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                         self.attn.proj.weight, self.attn.proj.bias, self.temporal_fc.weight,
-                        self.temporal_fc.bias, t, self.num_heads, s)
+                        self.temporal_fc.bias, t, self.num_heads, s, self.norm.eps)
 
 
 class DividedSpatialAttentionWithPreNorm(_DividedBase):
@@ -255,10 +264,12 @@ class DividedSpatialAttentionWithPreNorm(_DividedBase):
         x = _to_compute(query)
         b = x.shape[0]
         t = self.num_frames
+        if (x.shape[1] - 1) % t:
+            raise ValueError(f'{x.shape[1] - 1} tokens per clip are not a multiple of num_frames={t}')
         s = None if return_attention else _drop_scale(self.layer_drop, b * t, 3, x.device)
         return F_.SpaceAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                                     self.attn.proj.weight, self.attn.proj.bias, t, self.num_heads, s,
-                                    bool(return_attention))
+                                    bool(return_attention), self.norm.eps)
 
 
 class MultiheadAttentionWithPreNorm(nn.Module):
@@ -267,11 +278,9 @@ class MultiheadAttentionWithPreNorm(nn.Module):
     def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0., norm_layer=nn.LayerNorm,
                  layer_drop=dict(type=DropPath, dropout_p=0.), batch_first=False, **kwargs):
         super().__init__()
-        if norm_layer is not nn.LayerNorm:
-            raise NotImplementedError('vtx: only nn.LayerNorm is supported as norm_layer')
         self.embed_dims = embed_dims
         self.num_heads = num_heads
-        self.norm = norm_layer(embed_dims)
+        self.norm = _build_norm(norm_layer, embed_dims)
         self.attn = Attention(embed_dims, num_heads, qkv_bias=True, attn_drop=attn_drop)
         self.proj_drop = nn.Dropout(proj_drop)
         self.layer_drop = _build_layer_drop(layer_drop)
@@ -285,7 +294,7 @@ class MultiheadAttentionWithPreNorm(nn.Module):
         s = None if return_attention else _drop_scale(self.layer_drop, x.shape[0], 3, x.device)
         return F_.SelfAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                                    self.attn.proj.weight, self.attn.proj.bias, self.num_heads, s,
-                                   bool(return_attention))
+                                   bool(return_attention), self.norm.eps)
 
 
 class FFNWithPreNorm(nn.Module):
@@ -295,12 +304,12 @@ class FFNWithPreNorm(nn.Module):
                  norm_layer=nn.LayerNorm, dropout_p=0., layer_drop=None, **kwargs):
         super().__init__()
         assert num_layers >= 2, f'num_layers should be no less than 2. got {num_layers}.'
-        if num_layers != 2 or act_layer is not nn.GELU or norm_layer is not nn.LayerNorm:
-            raise NotImplementedError('vtx: FFN supports num_layers=2, nn.GELU, nn.LayerNorm only')
+        if num_layers != 2 or act_layer is not nn.GELU:
+            raise NotImplementedError('vtx: FFN supports num_layers=2 and nn.GELU only')
         self.embed_dims = embed_dims
         self.hidden_channels = hidden_channels
         self.num_layers = num_layers
-        self.norm = norm_layer(embed_dims)
+        self.norm = _build_norm(norm_layer, embed_dims)
         layers = []
         in_channels = embed_dims
         for _ in range(num_layers - 1):
@@ -318,7 +327,8 @@ class FFNWithPreNorm(nn.Module):
         x = _to_compute(x)
         s = _drop_scale(self.layer_drop, x.shape[0], x.ndim, x.device)
         fc1, fc2 = self.layers[0][0], self.layers[1]
-        return F_.FFNFn.apply(x, self.norm.weight, self.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, s)
+        return F_.FFNFn.apply(x, self.norm.weight, self.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, s,
+                              self.norm.eps)
 
 
 class BasicTransformerBlock(nn.Module):

@@ -51,6 +51,11 @@ class GemmTnDesc(C.Structure):
     ]
 
 
+class MtTensor(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p), ('n', C.c_long),
+                ('lr', C.c_float), ('wd', C.c_float)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ('dtype', C.c_int), ('mode', C.c_int),
@@ -108,6 +113,10 @@ SIGNATURES = {
     'vtx_maskfeat_blend_bwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_fwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_bwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, cf, vp, cl, vp]),
+    'vtx_mt_chunks': (ci, [cl]),
+    'vtx_mt_grad_norms': (ci, [vp, vp, ci, ci, vp, vp, vp]),
+    'vtx_mt_sgd_step': (ci, [vp, vp, ci, ci, vp, cf, cf, ci, ci, vp]),
+    'vtx_mt_adamw_step': (ci, [vp, vp, ci, ci, vp, cf, cf, cf, cf, ci, vp]),
     'vtx_selftest': (ci, [C.c_char_p, sz]),
 }
 

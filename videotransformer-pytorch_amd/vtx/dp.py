@@ -56,6 +56,9 @@ class GradBuckets:
     def _make_hook(self, bi):
         def hook(_p):
             b = self.buckets[bi]
+            if b['pending'] <= 0:
+                raise RuntimeError('GradBuckets: a gradient arrived for a bucket whose all-reduce was already '
+                                   'launched -- call zero() before every backward (one backward per step)')
             b['pending'] -= 1
             if b['pending'] == 0:
                 self._launch(b)
@@ -109,8 +112,11 @@ def broadcast_parameters(module, src=0, group=None):
     """One-time rank-0 -> all parameter broadcast (what DDP does at wrap time)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)
+    from . import functions
+    functions.clear_weight_cache()          # the staged bf16 W / W^T copies of the old values are stale
 
 
 def shard_clips(global_batch, rank, world):

@@ -19,22 +19,27 @@ _wcache = {}
 
 def weights(p, dtype, need_t=None):
     """(W, W^T) copies of Linear weight ``p`` [out,in] in ``dtype``; cached on the parameter OBJECT
-    (weak reference) until its version counter moves.  Forward passes fetch both copies and hand
-    W^T to backward through ctx.save_for_backward (ctx.saved_tensors returns new tensor objects, and
-    storage addresses are recycled between models, so neither id() nor data_ptr() of a saved tensor
-    is a safe cache key)."""
+    (weak reference).  A cached copy is reused only while the parameter's version counter, storage
+    address and device are unchanged: in-place updates through ``p`` (optimizers, ``copy_`` under
+    no_grad) bump the version; ``p.data = ...``, ``module.to(device)`` and re-allocation change the
+    address or device.  An update written through ``p.data`` IN PLACE (``p.data.copy_(...)``, EMA
+    loops) changes none of the three -- such code must call ``clear_weight_cache()`` afterwards
+    (``vtx.dp.broadcast_parameters`` does).  Forward passes fetch both copies and hand W^T to backward
+    through ctx.save_for_backward (ctx.saved_tensors returns new tensor objects, and storage addresses
+    are recycled between models, so neither id() nor data_ptr() of a saved tensor alone is a safe key)."""
     if need_t is None:          # NB: grad mode is off inside autograd.Function.forward -- callers there pass
         need_t = torch.is_grad_enabled()   # any(ctx.needs_input_grad) explicitly
     key = (id(p), dtype)
+    stamp = (p._version, p.data_ptr(), p.device)
     hit = _wcache.get(key)
-    if hit is not None and hit[0]() is p and hit[1] == p._version and (hit[3] is not None or not need_t):
+    if hit is not None and hit[0]() is p and hit[1] == stamp and (hit[3] is not None or not need_t):
         return hit[2], hit[3]
     w2d = p.detach().reshape(p.shape[0], -1)
     wc, wt = ops.cast_transpose(w2d, dtype, want_c=True, want_t=need_t)
     if len(_wcache) > 4096:                       # dead parameters: drop stale entries
         for k in [k for k, v in _wcache.items() if v[0]() is None]:
             del _wcache[k]
-    _wcache[key] = (weakref.ref(p), p._version, wc, wt)
+    _wcache[key] = (weakref.ref(p), stamp, wc, wt)
     return wc, wt
 
 
@@ -61,7 +66,7 @@ class TimeAttnFn(torch.autograd.Function):
     (reference transformer.py:234-282): proj and temporal_fc are two GEMMs with DropPath between them."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec):
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec, eps=1e-5):
         x = _chk(x)
         B, N1, D = x.shape
         N = N1 - 1
@@ -72,7 +77,7 @@ class TimeAttnFn(torch.autograd.Function):
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
@@ -127,7 +132,7 @@ class TimeAttnFn(torch.autograd.Function):
         d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
         ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None)
 
 
 class SpaceAttnFn(torch.autograd.Function):
@@ -137,7 +142,7 @@ class SpaceAttnFn(torch.autograd.Function):
     clip instead of once per frame); only the attention kernel regroups rows."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, T, heads, scale_vec, want_probs):
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, T, heads, scale_vec, want_probs, eps=1e-5):
         x = _chk(x)
         B, N1, D = x.shape
         N = N1 - 1
@@ -148,7 +153,7 @@ class SpaceAttnFn(torch.autograd.Function):
         xn = _empty((M1, D), x)
         mean = _empty((M1,), x, torch.float32)
         rstd = _empty((M1,), x, torch.float32)
-        ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M1, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M1, 3 * D, D, bias=qkv_b)
@@ -204,7 +209,7 @@ class SpaceAttnFn(torch.autograd.Function):
         d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
         d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M1, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None)
 
 
 class SelfAttnFn(torch.autograd.Function):
@@ -212,7 +217,7 @@ class SelfAttnFn(torch.autograd.Function):
     x [Bn, L, D] -> x + DropPath(proj(attn(LN(x))))."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, heads, scale_vec, want_probs):
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, heads, scale_vec, want_probs, eps=1e-5):
         x = _chk(x)
         Bn, L, D = x.shape
         M = Bn * L
@@ -221,7 +226,7 @@ class SelfAttnFn(torch.autograd.Function):
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
@@ -267,14 +272,14 @@ class SelfAttnFn(torch.autograd.Function):
         d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
         d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None)
 
 
 class FFNFn(torch.autograd.Function):
     """FFNWithPreNorm.forward with num_layers == 2 (reference transformer.py:516-523)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale_vec):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale_vec, eps=1e-5):
         x = _chk(x)
         D = x.shape[-1]
         M = x.numel() // D
@@ -284,7 +289,7 @@ class FFNFn(torch.autograd.Function):
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, 1e-5, xn, D, IDENT, mean, rstd)
+        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         w1c, w1T = weights(w1, dtp, any(ctx.needs_input_grad))
         h = _empty((M, Hd), x)
         g = _empty((M, Hd), x)
@@ -321,7 +326,7 @@ class FFNFn(torch.autograd.Function):
         d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
         d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
-        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None)
+        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None)
 
 
 class TokensFn(torch.autograd.Function):
@@ -342,6 +347,14 @@ class TokensFn(torch.autograd.Function):
         Tq = T // ts
         P = (H // ps) * (W // ps)
         K = Cc * ts * ps * ps
+        # the embedding tables are indexed by patch and frame: a clip with another grid or frame count than the
+        # model was built for would read out of bounds (the reference raises a broadcast error here)
+        if pos_embed.shape[-2] != 1 + P:
+            raise ValueError(f'clip has {P} patches per frame but pos_embed holds {pos_embed.shape[-2] - 1}')
+        if time_embed is not None and layout == 'pt' and time_embed.shape[-2] != Tq:
+            raise ValueError(f'clip has {Tq} (tubelet) frames but time_embed holds {time_embed.shape[-2]}')
+        if T % ts:
+            raise ValueError(f'{T} frames are not a multiple of the tubelet size {ts}')
         wc, _ = weights(conv_w, dtype, False)
         if layout == 'pt':
             rows = ops.patch_rows(clip, dtype, ps, ts, frame_major=False)        # [(b p t), K]
@@ -461,8 +474,15 @@ class LayerNormFn(torch.autograd.Function):
         return dx, d_w, d_b, None, None
 
 
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x @ W^T + b on [M, K] rows (decoder_pred / classification head)."""
+    """y = x @ W^T + b on [M, K] rows (decoder_pred / classification head).  The GEMM kernels move
+    16-byte vectors, so an output width that is not a multiple of 8 (174 / 101 / 51-class heads,
+    MaskFeat's default feature_dim=10) runs zero-padded to the next multiple and is sliced back
+    (padding / slicing of these [rows, classes]-sized tensors is plain tensor plumbing)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -470,28 +490,47 @@ class LinearFn(torch.autograd.Function):
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
-        wc, wT = weights(w, x.dtype, any(ctx.needs_input_grad))
-        y = _empty(tuple(x.shape[:-1]) + (N,), x)
-        ops.gemm_nt(x, wc, y, M, N, K, bias=b)
+        N8 = _pad8(N)
+        need_t = any(ctx.needs_input_grad)
+        if N8 == N:
+            wc, wT = weights(w, x.dtype, need_t)
+            bias = b
+        else:
+            w_pad = torch.zeros(N8, K, dtype=torch.float32, device=w.device)
+            w_pad[:N].copy_(w.detach().reshape(N, K))
+            wc, wT = ops.cast_transpose(w_pad, x.dtype, want_c=True, want_t=need_t)
+            bias = None
+            if b is not None:
+                bias = torch.zeros(N8, dtype=torch.float32, device=w.device)
+                bias[:N].copy_(b.detach())
+        y = _empty((M, N8), x)
+        ops.gemm_nt(x, wc, y, M, N8, K, bias=bias)
         ctx.save_for_backward(x, *([wT] if wT is not None else []))
         ctx.has_bias = b is not None
         ctx.N = N
-        return y
+        if N8 != N:
+            y = y[:, :N]
+        return y.reshape(tuple(x.shape[:-1]) + (N,))
 
     @staticmethod
     def backward(ctx, dy):
         x, wT = ctx.saved_tensors
-        dy = _chk(dy)
         K = x.shape[-1]
         M = x.numel() // K
         N = ctx.N
+        N8 = _pad8(N)
+        dy = dy.reshape(M, N)
+        if N8 != N:
+            dy = torch.nn.functional.pad(dy, (0, N8 - N))
+        dy = _chk(dy)
         if ctx.has_bias:
-            d_w, d_b = ops.gemm_tn(dy, x, M, N, K, want_colsum=True)
+            d_w, d_b = ops.gemm_tn(dy, x, M, N8, K, want_colsum=True)
+            d_b = d_b[:N]
         else:
-            d_w, d_b = ops.gemm_tn(dy, x, M, N, K), None
+            d_w, d_b = ops.gemm_tn(dy, x, M, N8, K), None
         dx = torch.empty_like(x)
-        ops.gemm_nt(dy, wT, dx, M, K, N)
-        return dx, d_w, d_b
+        ops.gemm_nt(dy, wT, dx, M, K, N8)
+        return dx, d_w[:N], d_b
 
 
 class CastFn(torch.autograd.Function):

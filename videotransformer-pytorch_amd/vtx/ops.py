@@ -59,30 +59,42 @@ def clsmap(n_tokens):
     return RowMap(1, int(n_tokens), 0)
 
 
-# ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream ----
+# ---- optional per-launch timing (bench.py rooflines): HIP events on the launch stream ----
 _prof = None
 
 
 def profile_start(classes=('gemm_nt',)):
+    """Time every launch of the named kernel classes with a pair of HIP events on the launch stream
+    (torch.cuda.Event records on torch's current stream, which is the stream the kernels are launched on)."""
     global _prof
     _prof = {c: [] for c in classes}
 
 
 def profile_stop():
-    """-> {class: (n_launches, total_ms, total_work)}; call after torch.cuda.synchronize()."""
+    """-> {class: {shape_key: [launches, total_ms, flops, algorithmic_bytes]}}; call after torch.cuda.synchronize()."""
     global _prof
     out = {}
     for c, recs in (_prof or {}).items():
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-        out[c] = (len(recs), ms, sum(w for _, _, w in recs))
+        per = out.setdefault(c, {})
+        for e0, e1, key, fl, by in recs:
+            r = per.setdefault(key, [0, 0.0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += e0.elapsed_time(e1)
+            r[2] += fl
+            r[3] += by
     _prof = None
     return out
 
 
+def profile_totals(per_class):
+    """{class: {key: [n, ms, flops, bytes]}} -> {class: (n, ms, flops, bytes)}."""
+    return {c: tuple(sum(v[i] for v in d.values()) for i in range(4)) for c, d in per_class.items()}
+
+
 class _timed:
-    def __init__(self, cls, work):
+    def __init__(self, cls, flops=0.0, nbytes=0.0, key=''):
         self.on = _prof is not None and cls in _prof
-        self.cls, self.work = cls, work
+        self.cls, self.rec = cls, (key, float(flops), float(nbytes))
 
     def __enter__(self):
         if self.on:
@@ -93,7 +105,7 @@ class _timed:
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            _prof[self.cls].append((self.e0, self.e1, self.work))
+            _prof[self.cls].append((self.e0, self.e1) + self.rec)
 
 
 def _f32(t):
@@ -105,7 +117,7 @@ def _f32(t):
 # ------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, rows, D, ldx, xmap, gamma, beta, eps, y, ldy, ymap=IDENT, mean=None, rstd=None):
     need_cuda(x, y, gamma, beta)
-    with _timed('ln_fwd', 2.0 * rows * D * x.element_size()):
+    with _timed('ln_fwd', nbytes=rows * D * (x.element_size() + y.element_size()), key=f'{rows}x{D}'):
         call('vtx_layernorm_fwd', dt(x), rows, D, ptr(x), ldx, xmap, ptr(_f32(gamma)), ptr(_f32(beta)), float(eps),
              ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
 
@@ -114,7 +126,7 @@ def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dre
     need_cuda(dy, x, dx)
     ws_bytes = _lib.load().vtx_layernorm_bwd_workspace(rows, D)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-    with _timed('ln_bwd', (4.0 if dres is not None else 3.0) * rows * D * x.element_size()):
+    with _timed('ln_bwd', nbytes=(4.0 if dres is not None else 3.0) * rows * D * x.element_size(), key=f'{rows}x{D}'):
         call('vtx_layernorm_bwd', dt(x), rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd),
              ptr(gamma), ptr(dres), ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, stream())
 
@@ -157,7 +169,26 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
     if _lib._TRACE:
         import sys
         sys.stderr.write(f'[vtx]   gemm_nt M={M} N={N} K={K} lda={d.lda} ldc={d.ldc} A={tuple(A.shape)} B={tuple(B.shape)} C={tuple(Cout.shape)} amap=({amap.grp},{amap.skip},{amap.base}) cmap=({cmap.grp},{cmap.skip},{cmap.base}) bias={bias is not None} rs={row_scale is not None} R={R is not None} split={split_row}\n')
-    with _timed('gemm_nt', 2.0 * M * N * K):
+    if _prof is not None and 'gemm_nt' in _prof:
+        # algorithmic bytes: every operand the launch must touch once (A, weight, C, and what the epilogue
+        # reads or writes besides: residual, GELU' input, pre-activation copy)
+        es = A.element_size()
+        nb = (M * K + N * K + M * N) * es
+        tags = ''
+        if C2 is not None:
+            nb += M * N * es
+            tags += '+preact'
+        if dgelu_in is not None:
+            nb += M * N * es
+            tags += "+gelu'"
+        if R is not None:
+            nb += (min(M, r_period) if r_period else M) * N * es
+            tags += '+res'
+        if row_scale is not None:
+            tags += '+scale'
+        with _timed('gemm_nt', 2.0 * M * N * K, nb, f'{M}x{N}x{K}{tags}'):
+            call('vtx_gemm_nt', C.byref(d), stream())
+    else:
         call('vtx_gemm_nt', C.byref(d), stream())
 
 
@@ -178,7 +209,7 @@ def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDEN
     d.C = ptr(out); d.ldc = N2; d.accumulate = int(bool(accumulate))
     d.workspace = ptr(ws); d.ws_bytes = ws_bytes
     d.colsum = ptr(cs); d.colsum_accumulate = 0
-    with _timed('gemm_tn', 2.0 * M * N1 * N2):
+    with _timed('gemm_tn', 2.0 * M * N1 * N2, M * (N1 + N2) * A.element_size() + N1 * N2 * 4, f'{M}x{N1}x{N2}'):
         call('vtx_gemm_tn', C.byref(d), stream())
     return (out, cs) if want_colsum else out
 
@@ -189,7 +220,7 @@ def colsum(A, M, N, lda=None, amap=IDENT, out=None, accumulate=False):
         out = torch.empty(N, dtype=torch.float32, device=A.device)
     ws_bytes = _lib.load().vtx_colsum_workspace(M, N)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
-    with _timed('colsum', 1.0 * M * N * A.element_size()):
+    with _timed('colsum', nbytes=1.0 * M * N * A.element_size(), key=f'{M}x{N}'):
         call('vtx_colsum', dt(A), M, N, ptr(A), N if lda is None else lda, amap, ptr(out), int(bool(accumulate)),
              ptr(ws), ws_bytes, stream())
     return out
@@ -210,7 +241,10 @@ def _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B=0, T=0, P=0, probs=Non
 def attn_fwd(qkv, out, lse, mode, S, L, H, hd, scale, B=0, T=0, P=0, probs=None):
     need_cuda(qkv, out, lse)
     d = _attn_desc(qkv, out, lse, mode, S, L, H, hd, scale, B, T, P, probs)
-    with _timed('attn_fwd', 4.0 * S * H * L * L * hd):
+    kind = 'space' if mode == _lib.ATTN_SPACE else ('time' if L <= 32 else 'seq')
+    rows = S * L                       # algorithmic bytes: read q,k,v, write o (+ fp32 log-sum-exp)
+    with _timed(f'attn_fwd_{kind}', 4.0 * S * H * L * L * hd, rows * H * hd * 4 * qkv.element_size() + rows * H * 4,
+                f'{S}x{L}x{H}'):
         call('vtx_attn_fwd', C.byref(d), stream())
 
 
@@ -223,7 +257,10 @@ def attn_bwd(qkv, out, lse, dout, dqkv, mode, S, L, H, hd, scale, B=0, T=0, P=0,
     b.dqkv_cls = ptr(dqkv_cls)
     delta = torch.empty(S * H * L, dtype=torch.float32, device=qkv.device)
     b.delta = ptr(delta)
-    with _timed('attn_bwd', 10.0 * S * H * L * L * hd):
+    kind = 'space' if mode == _lib.ATTN_SPACE else ('time' if L <= 32 else 'seq')
+    rows = S * L                       # read q,k,v,o,do, write dq,dk,dv
+    with _timed(f'attn_bwd_{kind}', 10.0 * S * H * L * L * hd, rows * H * hd * 8 * qkv.element_size() + rows * H * 4,
+                f'{S}x{L}x{H}'):
         call('vtx_attn_bwd', C.byref(b), stream())
 
 
@@ -358,8 +395,9 @@ def patch_rows(clip, dtype, ps, ts, frame_major):
         rows = torch.empty(B * (T // ts) * (H // ps) * (W // ps), K, dtype=dtype, device=clip.device)
         mean = (C.c_float * 3)(*_input_norm[0])
         std = (C.c_float * 3)(*_input_norm[1])
-        call('vtx_patch_rows_u8', _DT[dtype], B, T, H, W, ps, ts, ptr(clip), mean, std, ptr(rows), K, int(frame_major),
-             stream())
+        with _timed('patch_rows', nbytes=clip.numel() + rows.numel() * rows.element_size(), key=f'u8 {B}x{T}'):
+            call('vtx_patch_rows_u8', _DT[dtype], B, T, H, W, ps, ts, ptr(clip), mean, std, ptr(rows), K, int(frame_major),
+                 stream())
         return rows
     if clip.dtype != torch.float32:
         clip = clip.float()
@@ -367,7 +405,8 @@ def patch_rows(clip, dtype, ps, ts, frame_major):
     B, T, Cc, H, W = clip.shape
     K = Cc * ts * ps * ps
     rows = torch.empty(B * (T // ts) * (H // ps) * (W // ps), K, dtype=dtype, device=clip.device)
-    call('vtx_patch_rows', _DT[dtype], B, T, Cc, H, W, ps, ts, ptr(clip), ptr(rows), K, int(frame_major), stream())
+    with _timed('patch_rows', nbytes=clip.numel() * 4 + rows.numel() * rows.element_size(), key=f'f32 {B}x{T}'):
+        call('vtx_patch_rows', _DT[dtype], B, T, Cc, H, W, ps, ts, ptr(clip), ptr(rows), K, int(frame_major), stream())
     return rows
 
 
@@ -402,5 +441,7 @@ def hog_fwd(frames, want_bins=False):
     F, H, W, _ = frames.shape
     out = torch.empty(F, H // 16, W // 16, 108, dtype=torch.float64, device=frames.device)
     bins = torch.empty(F, 3, H, W, dtype=torch.int32, device=frames.device) if want_bins else None
-    call('vtx_hog_fwd', ptr(frames), F, H, W, ptr(hog_table(frames.device)), ptr(out), ptr(bins), stream())
+    table = hog_table(frames.device)
+    with _timed('hog', nbytes=frames.numel() + out.numel() * 8, key=f'{F}x{H}x{W}'):
+        call('vtx_hog_fwd', ptr(frames), F, H, W, ptr(table), ptr(out), ptr(bins), stream())
     return (out, bins) if want_bins else out

@@ -1,0 +1,165 @@
+"""Multi-tensor optimizer step + per-parameter gradient norms / clipping on libvtx kernels.
+
+The step right after backward.  The reference builds ``torch.optim.SGD(momentum=0.9, nesterov=True)``
+or ``AdamW(betas=(0.9, 0.999))`` over a no-decay / decay pair of parameter groups (optimizer.py:21-62),
+clips every parameter's gradient to ``clip_grad`` by its own norm with ~250 ``torch.norm`` launches
+(model_trainer.py:155-170) and rewrites the decay group's ``weight_decay`` every step
+(model_trainer.py:147-151).  ``FusedSGD`` / ``FusedAdamW`` are ``torch.optim.Optimizer`` subclasses
+with the same ``param_groups`` / ``state_dict`` surface (so that code keeps working) whose ``step()``
+is three kernel launches over a device table of (param, grad, state) pointers: chunk sums of
+squares, per-parameter norms (+ the norm of norms the reference logs), clipped update.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+
+
+class _FusedBase(torch.optim.Optimizer):
+    def __init__(self, params, defaults, clip_grad=None):
+        if hasattr(params, 'buckets'):                  # a vtx.dp.GradBuckets: its parameters, in bucket order
+            params = [p for b in params.buckets for p in b['params']]
+        super().__init__(params, defaults)
+        self.clip_grad = clip_grad
+        self.last_grad_norm = None                      # device scalar: ||(per-parameter norms)||_2 of the last step
+        self._key = None
+        self._n_steps = 0
+
+    # ---- device tables --------------------------------------------------------------------------
+    def _entries(self):
+        ent = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                    raise TypeError('vtx.optim: parameters and gradients must be float32')
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise ValueError('vtx.optim: parameters and gradients must be contiguous')
+                ent.append((p, gi))
+        return ent
+
+    def _state_tensors(self, p):
+        raise NotImplementedError
+
+    def _build(self, ent):
+        lib = _lib.load()
+        dev = ent[0][0].device
+        ops.need_cuda(*[p for p, _ in ent])
+        tab = (_lib.MtTensor * len(ent))()
+        starts = [0]
+        for i, (p, gi) in enumerate(ent):
+            s1, s2 = self._state_tensors(p)
+            tab[i].p, tab[i].g = p.data_ptr(), p.grad.data_ptr()
+            tab[i].s1, tab[i].s2 = s1.data_ptr(), (s2.data_ptr() if s2 is not None else None)
+            tab[i].n = p.numel()
+            starts.append(starts[-1] + lib.vtx_mt_chunks(p.numel()))
+        self._tab_host = tab
+        self._groups_of = [gi for _, gi in ent]
+        self._n_chunks = starts[-1]
+        self._chunk_start = torch.tensor(starts, dtype=torch.int32).to(dev)
+        self._tab_dev = torch.empty(C.sizeof(tab), dtype=torch.uint8, device=dev)
+        self._partial = torch.empty(self._n_chunks, dtype=torch.float32, device=dev)
+        self._norms = torch.zeros(len(ent) + 1, dtype=torch.float32, device=dev)
+        self._hyper = None
+
+    def _sync_tables(self):
+        ent = self._entries()
+        if not ent:
+            return False
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p, _ in ent)
+        if key != self._key:
+            self._build(ent)
+            self._key = key
+        hyper = tuple((float(g['lr']), float(g['weight_decay'])) for g in self.param_groups)
+        if hyper != self._hyper:                        # schedulers rewrite lr / weight_decay between steps
+            for i, gi in enumerate(self._groups_of):
+                self._tab_host[i].lr, self._tab_host[i].wd = hyper[gi]
+            raw = bytes(self._tab_host)
+            self._tab_dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8), non_blocking=False)
+            self._hyper = hyper
+        return True
+
+    def grad_norm(self):
+        """||(||g_0||, ||g_1||, ...)||_2 over the parameters that have gradients, as a device scalar -- what
+        the reference's clip_gradients returns (model_trainer.py:169)."""
+        if not self._sync_tables():
+            return None
+        _lib.call('vtx_mt_grad_norms', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
+                  self._n_chunks, self._partial.data_ptr(), self._norms.data_ptr(), ops.stream())
+        return self._norms[-1]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._sync_tables():
+            return loss
+        clip = float(self.clip_grad) if self.clip_grad else 0.0
+        if clip > 0.0:
+            self.last_grad_norm = self.grad_norm()
+        self._n_steps += 1
+        self._launch(clip)
+        self._bump_versions()
+        return loss
+
+    def _bump_versions(self):
+        # The kernels update parameter storage behind autograd's back; staged bf16 weight copies are
+        # keyed on the version counter (vtx.functions.weights), so bump it the documented way:
+        # an in-place no-op on a zero-element view costs nothing and increments the shared counter.
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    p.view(-1)[:0].zero_()
+
+    def _launch(self, clip):
+        raise NotImplementedError
+
+
+class FusedSGD(_FusedBase):
+    """torch.optim.SGD(lr, momentum, nesterov, weight_decay; dampening 0) as one multi-tensor kernel."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=0.0, clip_grad=None):
+        if nesterov and momentum <= 0:
+            raise ValueError('Nesterov momentum requires a momentum')
+        super().__init__(params, dict(lr=lr, momentum=momentum, nesterov=nesterov, weight_decay=weight_decay), clip_grad)
+
+    def _state_tensors(self, p):
+        st = self.state[p]
+        if 'momentum_buffer' not in st:
+            # zero-initialised: the first update gives buf = momentum * 0 + g = g, torch's first-step rule
+            st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st['momentum_buffer'], None
+
+    def _launch(self, clip):
+        g0 = self.param_groups[0]
+        if any(g['momentum'] != g0['momentum'] or g['nesterov'] != g0['nesterov'] for g in self.param_groups):
+            raise NotImplementedError('vtx.optim.FusedSGD: momentum / nesterov must be the same in every group')
+        _lib.call('vtx_mt_sgd_step', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
+                  self._n_chunks, self._norms.data_ptr(), clip, float(g0['momentum']), int(bool(g0['nesterov'])),
+                  0, ops.stream())
+
+
+class FusedAdamW(_FusedBase):
+    """torch.optim.AdamW(lr, betas, eps, weight_decay) as one multi-tensor kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_grad=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay), clip_grad)
+
+    def _state_tensors(self, p):
+        st = self.state[p]
+        if 'exp_avg' not in st:
+            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st['exp_avg'], st['exp_avg_sq']
+
+    def _launch(self, clip):
+        g0 = self.param_groups[0]
+        if any(g['betas'] != g0['betas'] or g['eps'] != g0['eps'] for g in self.param_groups):
+            raise NotImplementedError('vtx.optim.FusedAdamW: betas / eps must be the same in every group')
+        _lib.call('vtx_mt_adamw_step', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
+                  self._n_chunks, self._norms.data_ptr(), clip, float(g0['betas'][0]), float(g0['betas'][1]),
+                  float(g0['eps']), self._n_steps, ops.stream())
