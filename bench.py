@@ -280,6 +280,8 @@ def main():
         names = ('gemm_nt', 'gemm_tn', 'attn_fwd_time', 'attn_bwd_time', 'attn_fwd_space', 'attn_bwd_space', 'ln_fwd', 'ln_bwd',
                  'colsum', 'patch_rows', 'hog')
         nb = 2
+        frames_u8 = torch.randint(0, 256, (64, 224, 224, 3), dtype=torch.uint8, device=dev)   # MaskFeat HOG targets
+        ops.hog_fwd(frames_u8)                          # builds / uploads the magnitude table once
         ops.profile_start(names)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -287,7 +289,6 @@ def main():
             step()
         torch.cuda.synchronize()
         step_ms = (time.perf_counter() - t1) / nb * 1e3
-        frames_u8 = torch.randint(0, 256, (64, 224, 224, 3), dtype=torch.uint8, device=dev)   # MaskFeat HOG targets
         for _ in range(nb):
             ops.hog_fwd(frames_u8)
         torch.cuda.synchronize()

@@ -45,6 +45,7 @@ for step in range(2):
     model(X[mine]).square().sum().backward()                # sum over the shard
     buckets.finish()                                        # -> mean over ranks of the shard sums
 got = [p.grad.clone() for p in params]
+buckets.remove()                                            # detach the hooks: the next backward is the single-process reference
 for p in params:
     p.grad = None
 ref_model = model

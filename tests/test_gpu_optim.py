@@ -86,6 +86,7 @@ def test_build_optimizer_groups_like_the_reference():
     g0 = {names[id(p)] for p in opt.param_groups[0]['params']}
     g1 = {names[id(p)] for p in opt.param_groups[1]['params']}
     assert opt.param_groups[0]['weight_decay'] == 0 and opt.param_groups[1]['weight_decay'] == 0.05
-    assert {'pos_embed', 'cls_token', 'time_embed', 'norm.weight', 'patch_embed.projection.bias'} <= g0
-    assert 'patch_embed.projection.weight' in g1 and all(n.endswith('weight') for n in g1)
+    assert {'pos_embed', 'cls_token', 'norm.weight', 'patch_embed.projection.bias'} <= g0
+    # time_embed is 3-D and not among the reference's no-decay keywords: it IS decayed (optimizer.py:51-58)
+    assert 'patch_embed.projection.weight' in g1 and all(n.endswith('weight') or n == 'time_embed' for n in g1)
     assert len(g0) + len(g1) == len(names)
