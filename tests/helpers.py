@@ -9,19 +9,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 REPORT = os.path.join(ROOT, 'gpurun_out', 'parity_report.txt')
 
-# parity bars (BASELINE.json north_star): fp32 path 1e-3 relative to the reference's fp32 CPU
-# result; bf16 path is reported against the same fp32 oracle with the documented looser bar
-# (a bf16 autocast CPU run of the reference itself deviates by 8.6e-3).
+# Parity bars (BASELINE.json north_star).
+#   fp32 path: 1e-3 relative to the reference's fp32 CPU result (measured ~1e-6).
+#   bf16 path: reported against the same fp32 reference.  Calibration (tests/golden/tsf_b_t8_autocast.npz, written by
+#   tests/golden/make_golden_r2.py): the REFERENCE ITSELF under torch.autocast(bfloat16) -- the AMP class it trains in,
+#   model_pretrain.py:203 -- deviates from its own fp32 run by 9.6e-3 on the outputs (max-rel) and by 8.9e-3 median /
+#   1.76e-2 worst relative L2 on the 247 parameter gradients of TimeSformer-B 8x224^2.  This path measures 1.1e-2 on the
+#   outputs and 9.1e-3 median / 1.35e-2 worst on the gradients (gpurun_out/r2_bf16_error_map.txt, profiles/): the same
+#   class.  tools/precision_study.py shows why an fp32 residual stream is not needed for that: rounding the stream to
+#   bf16 after every sub-block, forward and backward, moves the reference's autocast numbers by < 3 %.
 TOL_F32 = 1e-3
-TOL_BF16 = 3e-2
-# bf16 parameter gradients after 12 layers of bf16 backward: bar on the relative L2 error; single
-# elements may deviate by up to 2x that (checked too).  Calibration (TimeSformer-B 8x224^2, worst
-# tensor = layer-0 temporal proj weight): the reference run under torch.autocast(bfloat16) on CPU
-# deviates 1.6e-2 from its own fp32 run while keeping the residual stream, LayerNorm and softmax in
-# fp32; this path also STORES the residual stream and every activation gradient in bf16 and
-# measures 5.9e-2.  (An fp32 residual stream is listed as follow-up work in DESIGN.md.)
-TOL_BF16_GRAD = 8e-2
-ELEMENT_SLACK = 2.0
+TOL_BF16 = 1.5e-2          # outputs, max-abs error / max-abs reference
+TOL_BF16_GRAD = 2e-2       # parameter gradients, relative L2 (whole tensor, or 4096 strided samples of a large one)
+ELEMENT_SLACK = 3.0        # single gradient elements: within ELEMENT_SLACK * TOL_BF16_GRAD of max|ref|
+AUTOCAST_FACTOR = 2.0      # with a reference-autocast calibration: per tensor <= max(FACTOR * its autocast error, FLOOR)
+AUTOCAST_FLOOR = 1e-2
+NS = 4096                  # samples per large tensor in the round-2 goldens
 
 
 def gold(name):
@@ -60,31 +63,43 @@ def l2err(a, b):
     return (a - b).norm().item() / max(b.norm().item(), 1e-30)
 
 
-def compare_grads(prefix, named_grads, g, tol, exact_elements=False):
-    """named_grads: {param_name: grad tensor}; g: golden npz from make_golden.grads_summary.
+def sample_idx(numel):
+    step = max(numel // NS, 1)
+    return torch.arange(0, min(NS, numel)) * step
+
+
+def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_cal=False):
+    """named_grads: {param_name: grad tensor}; g: golden npz ('g:' whole small tensors, 'gs:' 4096 strided samples
+    or 'gh:' the first 256 elements of large ones, 'gn:' their norm and sum).
     fp32 path (exact_elements): every element within tol of max|ref| (the 1e-3 bar).
-    bf16 path: relative L2 error <= tol and every element within ELEMENT_SLACK*tol of max|ref|."""
+    bf16 path: relative L2 error <= tol and every element within ELEMENT_SLACK*tol of max|ref|; with autocast_cal
+    (golden holds 'ae:' = the reference's own autocast deviation per tensor) additionally each tensor within
+    max(AUTOCAST_FACTOR * ae, AUTOCAST_FLOOR) and the median no worse than 1.25x the reference's median."""
     worst_l2 = worst_max = 0.0
     n = 0
+    ours, theirs = [], []
     for k in g.files:
         if k.startswith('g:'):
-            got, ref = named_grads[k[2:]].detach().double().cpu(), torch.as_tensor(g[k]).double()
+            name = k[2:]
+            got, ref = named_grads[name].detach().double().cpu(), torch.as_tensor(g[k]).double()
             scale = ref.abs().max().item()
             scale_rms = 0.0
             norm_err = 0.0
-        elif k.startswith('gh:'):
+        elif k.startswith('gh:') or k.startswith('gs:'):
             name = k[3:]
             gn = g['gn:' + name]
             full = named_grads[name].detach().double().cpu()
-            got, ref = full.flatten()[:256], torch.as_tensor(g[k]).double()
-            # the stored head of a large tensor: scale by the larger of its own max and the tensor's rms
+            flat = full.flatten()
+            got = flat[:256] if k.startswith('gh:') else flat[sample_idx(flat.numel())]
+            ref = torch.as_tensor(g[k]).double()
+            # the stored part of a large tensor: scale by the larger of its own max and the tensor's rms
             scale_rms = gn[0] / (full.numel() ** 0.5)
             scale = max(ref.abs().max().item(), scale_rms)
             norm_err = abs(full.norm().item() - gn[0]) / max(gn[0], 1e-30)
         else:
             continue
         e_max = (got - ref).abs().max().item() / max(scale, 1e-30)
-        # L2 error relative to the larger of the compared slice's norm and the norm that many typical
+        # L2 error relative to the larger of the compared part's norm and the norm that many typical
         # (rms-sized) elements of the tensor would have -- a 256-element head can be atypically small
         ref_norm = max(ref.norm().item(), scale_rms * (ref.numel() ** 0.5))
         e_l2 = max((got - ref).norm().item() / max(ref_norm, 1e-30), norm_err)
@@ -92,8 +107,18 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False):
         worst_l2, worst_max = max(worst_l2, e_l2), max(worst_max, e_max)
         lim_max = tol if exact_elements else ELEMENT_SLACK * tol
         bad = e_max > lim_max or (not exact_elements and e_l2 > tol)
+        if autocast_cal and not exact_elements:
+            ae = float(g['ae:' + name])
+            ours.append(e_l2)
+            theirs.append(ae)
+            bad = bad or e_l2 > max(AUTOCAST_FACTOR * ae, AUTOCAST_FLOOR)
         if bad:
             report(f'FAIL {prefix} grad {k}: max-rel={e_max:.3e} l2-rel={e_l2:.3e}')
         assert not bad, f'{prefix}: grad {k} max-rel {e_max:.3e} l2-rel {e_l2:.3e} (tol {tol:g})'
-    report(f'ok   {prefix}: {n} parameter gradients, worst max-rel={worst_max:.3e} l2-rel={worst_l2:.3e} (tol {tol:g})')
+    extra = ''
+    if ours:
+        mo, mt = sorted(ours)[len(ours) // 2], sorted(theirs)[len(theirs) // 2]
+        extra = f'; median l2 {mo:.3e} vs reference-autocast median {mt:.3e} (worst {max(theirs):.3e})'
+        assert mo <= 1.25 * mt, f'{prefix}: median gradient error {mo:.3e} > 1.25 x the reference autocast median {mt:.3e}'
+    report(f'ok   {prefix}: {n} parameter gradients, worst max-rel={worst_max:.3e} l2-rel={worst_l2:.3e} (tol {tol:g}){extra}')
     return worst_max

@@ -1,9 +1,9 @@
 """Model-level parity of the HIP path (through the drop-in nn.Module API and the C ABI)
 against (a) the committed golden vectors generated from the reference and (b) the CPU oracle.
 
-Bars (tests/helpers.py): fp32 path 1e-3 relative (north_star); bf16 path 3e-2 on outputs and, on
-parameter gradients, 8e-2 relative L2 (calibration in tests/helpers.py) versus the same fp32 reference (a bf16-autocast CPU run of the
-reference itself deviates by 8.6e-3 after 12 layers).
+Bars (tests/helpers.py): fp32 path 1e-3 relative (north_star); bf16 path 1.5e-2 on outputs and 2e-2 relative L2
+on parameter gradients versus the same fp32 reference, calibrated against the reference's own bf16-autocast run
+(tsf_b_t8_autocast.npz: 9.6e-3 / 1.76e-2 worst), which the bf16 test of that configuration is also compared with.
 All weights come from oracle/synth.py: temporal_fc is NOT zero, so the temporal kernels matter.
 """
 import json
@@ -120,7 +120,7 @@ def test_timesformer_b_t8_train_vs_golden(prec, tol, gtol):
 @pytest.mark.parametrize('prec,tol,gtol', PRECS)
 def test_timesformer_b_t16_train_vs_golden(prec, tol, gtol):
     """The north_star's second clip shape: TimeSformer-B on 16x3x224x224, train mode with DropPath,
-    fwd+bwd against the reference's own run (tests/golden/make_golden_t16.py).  Temporal attention
+    fwd+bwd against the reference's own run (tests/golden/make_golden_r2.py).  Temporal attention
     here packs two 16-token sequences per 32-row MFMA tile."""
     import vtx
     import video_transformer as V
@@ -130,6 +130,51 @@ def test_timesformer_b_t16_train_vs_golden(prec, tol, gtol):
     y, grads = _train_step(m, synth.synth_clip(1, 16, seed=21), 9, 768)
     check(f'TimeSformer-B T=16 train {prec} out', y.cpu(), g['out'], tol)
     compare_grads(f'TimeSformer-B T=16 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
+
+
+def test_timesformer_b_t8_bf16_vs_reference_autocast():
+    """The benchmarked configuration and precision (BASELINE cfg 2, bf16) against the reference's fp32 run, with the
+    reference's OWN bf16-autocast run of the same step as the yardstick: every parameter gradient within 2x of the
+    deviation the reference's AMP shows for that tensor (floor 1e-2), the median within 1.25x, outputs within 1.3x."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision('bf16')
+    g = gold('tsf_b_t8_autocast.npz')
+    m, _ = _build(V.TimeSformer, 0, num_frames=8)
+    y, grads = _train_step(m, synth.synth_clip(1, 8, seed=1), 7, 768)
+    e = check('TimeSformer-B T=8 train bf16 out (r2 golden)', y.cpu(), g['out'], TOL_BF16)
+    ref_dev = relerr(g['out_autocast'], g['out'])
+    report(f'     reference autocast output deviation {ref_dev:.3e}, this path {e:.3e}')
+    assert e <= 1.3 * ref_dev, f'bf16 outputs deviate {e:.3e}, more than 1.3x the reference autocast run ({ref_dev:.3e})'
+    compare_grads('TimeSformer-B T=8 train bf16 vs reference autocast', grads, g, TOL_BF16_GRAD, autocast_cal=True)
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+def test_vivit_b_t16_train_vs_golden(prec, tol, gtol):
+    """BASELINE.json configs[2] at full size, TRAIN mode fwd+bwd: ViViT-B fact_encoder, Conv3d tubelets, 16x224^2,
+    batch 2 (so that the reference's `x[:b, 0]` cls quirk between the two encoders matters), all 231 gradients."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold('vivit_b_t16_train.npz')
+    m, _ = _build(V.ViViT, 0, num_frames=16)
+    y, grads = _train_step(m, synth.synth_clip(2, 16, seed=3), 17, 768)
+    check(f'ViViT-B T=16 train {prec} out', y.cpu(), g['out'], tol)
+    compare_grads(f'ViViT-B T=16 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+def test_timesformer_l_t96_train_vs_golden(prec, tol, gtol):
+    """BASELINE.json configs[4] geometry: TimeSformer-L (D 1024, 16 heads, hidden 4096) on 96x224^2 clips -- 18 817
+    tokens per clip, temporal attention over 96 frames, 96-frame cls mean -- at depth 2, train mode fwd+bwd."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold('tsf_l_t96_d2_train.npz')
+    m, _ = _build(V.TimeSformer, 0, num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=2)
+    y, grads = _train_step(m, synth.synth_clip(1, 96, seed=5), 19, 1024)
+    check(f'TimeSformer-L T=96 depth 2 train {prec} out', y.cpu(), g['out'], tol)
+    compare_grads(f'TimeSformer-L T=96 depth 2 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
@@ -143,6 +188,26 @@ def test_vivit_b_forward(prec, tol):
     with torch.no_grad():
         y = m(synth.synth_clip(2, 16, seed=3).to(DEV))
     check(f'ViViT-B fact_encoder {prec}', y.cpu(), gold('vivit_b_t16_eval.npz')['out'], tol)
+
+
+def test_block_recompute_gives_identical_gradients():
+    """vtx.set_recompute(True): every transformer block is re-run in backward instead of keeping its activations
+    (long-clip sizing, BASELINE cfg 5) -- same DropPath draws, bit-identical outputs and gradients."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision('bf16')
+    res = []
+    try:
+        for rc in (False, True):
+            vtx.set_recompute(rc)
+            m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
+            y, grads = _train_step(m, synth.synth_clip(3, 4, 3, 64, 64, seed=2), 11, 128)
+            res.append((y.detach().clone(), {k: v.clone() for k, v in grads.items()}))
+    finally:
+        vtx.set_recompute(False)
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
 def test_batch_and_length_properties():

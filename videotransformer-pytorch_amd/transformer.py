@@ -17,6 +17,7 @@ import numpy as np
 
 import torch
 import torch.nn as nn
+import torch.utils.checkpoint
 from torch.nn.modules.utils import _pair
 
 import vtx
@@ -390,9 +391,13 @@ class TransformerContainer(nn.Module):
 
     def forward(self, x, return_attention=False):
         last = self.num_transformer_layers - 1
+        recompute = vtx.recompute_enabled() and torch.is_grad_enabled() and not return_attention
         for idx, layer in enumerate(self.layers):
             if return_attention and idx >= last:
                 x = layer(x, return_attention=True)
+            elif recompute:
+                # the CPU generator state is saved and restored around the re-run: DropPath draws the same masks
+                x = torch.utils.checkpoint.checkpoint(layer, x, use_reentrant=False)
             else:
                 x = layer(x)
         return x

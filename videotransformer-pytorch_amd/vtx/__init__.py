@@ -32,3 +32,19 @@ def compute_dtype():
     if _precision == 'bf16':
         return torch.bfloat16
     return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+
+_recompute = False
+
+
+def set_recompute(on):
+    """Re-run every transformer block in backward instead of keeping its activations (torch.utils.checkpoint
+    around BasicTransformerBlock): trades ~1/3 more block compute for the ~0.8 GB per clip and layer that
+    TimeSformer-L on 96-frame clips saves for backward (BASELINE.json configs[4]; 288 GB holds ~12 such clips
+    without it).  The reference has no equivalent; off by default."""
+    global _recompute
+    _recompute = bool(on)
+
+
+def recompute_enabled():
+    return _recompute
