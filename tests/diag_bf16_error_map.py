@@ -2,7 +2,7 @@
 
     python tests/diag_bf16_error_map.py [frames] > gpurun_out/bf16_error_map.txt
 
-Runs TimeSformer-B (one clip, train mode, the seeds of tests/golden/tsf_b_t8_train.npz) through the
+Runs TimeSformer-B (one clip, train mode, the seeds of tests/golden/tsf_b_t8_autocast.npz) through the
 HIP path in fp32 (which matches the reference to ~1e-6, tests/test_gpu_models.py) and in bf16, and
 prints, per variant: the relative L2 error of the residual stream after every sub-block (forward),
 of the stream gradient entering every sub-block (backward), and of every parameter gradient (whole

@@ -81,12 +81,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'tsf_b_cfg1.npz'), **r)
     print('cfg1', r['out'].shape, float(np.abs(r['out']).max()))
 
-    # ---- cfg 2 shape: TimeSformer-B, T=8, B=1, train mode fwd+bwd ---------------------
+    # ---- cfg 2 shape: TimeSformer-B, T=8, B=1: eval forward + attention map ------------
     m = VT.TimeSformer(num_frames=8)
     sd = synth.synth_state_dict(synth.shapes_of(m), seed=0)
-    r = run_model(m, synth.synth_clip(1, 8, seed=1), sd, train=True, seed=7)
-    np.savez_compressed(os.path.join(HERE, 'tsf_b_t8_train.npz'), **r)
-    print('tsf_b_t8_train', len(r))
+    # (the train-mode fwd+bwd golden of this configuration is tsf_b_t8_autocast.npz, make_golden_r2.py)
     r = run_model(m, synth.synth_clip(1, 8, seed=1), sd, train=False, want_grads=False)
     m.zero_grad()
     with torch.no_grad():

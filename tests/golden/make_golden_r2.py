@@ -2,7 +2,7 @@
 
     python tests/golden/make_golden_r2.py [tsf_b_t8_ac] [tsf_b_t16] [vivit_b_t16] [tsf_l_t96]
 
-  tsf_b_t8_autocast.npz   TimeSformer-B 8x224^2 (the seeds of tsf_b_t8_train.npz): the reference's own fp32 run AND its
+  tsf_b_t8_autocast.npz   TimeSformer-B 8x224^2 (clip seed 1, torch seed 7): the reference's own fp32 run AND its
                           own torch.autocast(bfloat16) run -- per-parameter relative-L2 deviation of the autocast
                           gradients from the fp32 ones ('ae:'), the calibration of the bf16 parity bar
   tsf_b_t16_train.npz     TimeSformer-B 16x224^2, batch 1, train mode fwd+bwd (the north_star's second clip shape)

@@ -102,7 +102,7 @@ def test_timesformer_b_t8_train_vs_golden(prec, tol, gtol):
     import vtx
     import video_transformer as V
     vtx.set_precision(prec)
-    g = gold('tsf_b_t8_train.npz')
+    g = gold('tsf_b_t8_autocast.npz')                 # the fp32 run of the reference ('out', gradients) + its autocast run
     m, _ = _build(V.TimeSformer, 0, num_frames=8)
     y, grads = _train_step(m, synth.synth_clip(1, 8, seed=1), 7, 768)
     check(f'TimeSformer-B T=8 train {prec} out', y.cpu(), g['out'], tol)
