@@ -250,6 +250,30 @@ int vtx_maskfeat_loss_bwd(int dtype, int B, int Tq, int ts, int g, int Cf, const
                           const double* target, const uint8_t* cmask, const double* loss_out,
                           float gloss, void* dpred, long lddp, void* stream);
 
+/* ------------------------------------------- clip-batch mixing, classification loss, accuracy
+ * Mixup / CutMix of the clip batch in place (mixup.py:102-126; the numpy draws stay on the host): x is
+ * [B, per_clip] fp32 (a [B,T,C,H,W] batch), B even; clip b is mixed with clip B-1-b.
+ *   mixup : x[b] = x[b]*lam + x[B-1-b]*one_minus_lam  (both passed as the fp32 values ATen uses; separate
+ *           multiply / multiply / add roundings: bit-identical to the reference's mul_().add_())
+ *   cutmix: the box rows [yl,yh) x columns [xl,xh) of every one of the `planes` = T*C planes is swapped. */
+int vtx_mixup_batch(float* x, int B, long per_clip, float lam, float one_minus_lam, void* stream);
+int vtx_cutmix_batch(float* x, int B, int planes, int H, int W, int yl, int yh, int xl, int xh, void* stream);
+/* mixup_target (mixup.py:20-25): out[b][c] = v(b,c)*lam + v(B-1-b,c)*one_minus_lam, v = on_value at the label, else off_value. */
+int vtx_mixup_target(const long* labels, int B, int C, float on_value, float off_value, float lam, float one_minus_lam,
+                     float* out, void* stream);
+/* Softmax cross-entropy on fp32 logits [B,C] with EITHER soft targets [B,C] (timm SoftTargetCrossEntropy,
+ * model_trainer.py:87-88) or int64 labels (nn.CrossEntropyLoss, :91).  loss_rows[b] = sum_c -t log_softmax(x);
+ * loss_mean[0] (optional) = their mean, summed in a fixed order; lse[b] saved for backward.
+ * bwd: dlogits = grad_scale * grad_loss[0] * (softmax * sum_c t - t); grad_scale = 1/B for the mean, grad_loss =
+ * the upstream gradient of the scalar loss ON THE DEVICE (NULL = 1). */
+int vtx_softmax_xent_fwd(const float* logits, const float* soft_targets, const long* labels, int B, int C, float* loss_rows,
+                         float* lse, float* loss_mean, void* stream);
+int vtx_softmax_xent_bwd(const float* logits, const float* soft_targets, const long* labels, const float* lse, int B, int C,
+                         float grad_scale, const float* grad_loss, float* dlogits, void* stream);
+/* correct[0] += number of rows whose label is among the k largest scores (torchmetrics Accuracy(top_k),
+ * model_trainer.py:83-84,213-214); ties resolved like torch.topk (lower index first). */
+int vtx_topk_correct(const float* scores, const long* labels, int B, int C, int k, int* correct, void* stream);
+
 /* ------------------------------------------------- optimizer step / gradient clipping
  * The step right after backward (model_trainer.py:155-170 clip_gradients, :218-231; optimizer.py:31-38):
  * every parameter is one row of a DEVICE table; three launches per step whatever the parameter count.

@@ -113,6 +113,12 @@ SIGNATURES = {
     'vtx_maskfeat_blend_bwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_fwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_bwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, cf, vp, cl, vp]),
+    'vtx_mixup_batch': (ci, [vp, ci, cl, cf, cf, vp]),
+    'vtx_cutmix_batch': (ci, [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
+    'vtx_mixup_target': (ci, [vp, ci, ci, cf, cf, cf, cf, vp, vp]),
+    'vtx_softmax_xent_fwd': (ci, [vp, vp, vp, ci, ci, vp, vp, vp, vp]),
+    'vtx_softmax_xent_bwd': (ci, [vp, vp, vp, vp, ci, ci, cf, vp, vp, vp]),
+    'vtx_topk_correct': (ci, [vp, vp, ci, ci, ci, vp, vp]),
     'vtx_mt_chunks': (ci, [cl]),
     'vtx_mt_grad_norms': (ci, [vp, vp, ci, ci, vp, vp, vp]),
     'vtx_mt_sgd_step': (ci, [vp, vp, ci, ci, vp, cf, cf, ci, ci, vp]),

@@ -605,3 +605,42 @@ class RowScaleFn(torch.autograd.Function):
         dx = torch.empty_like(dy)
         ops.row_scale_copy(dy, dx, dy.numel() // D, D, s=s, rs=(ctx.rows_per, 1, 1, 0))
         return dx, None, None
+
+
+class SoftmaxXentFn(torch.autograd.Function):
+    """mean_b sum_c -t[b,c] log_softmax(logits[b])[c]: ``target`` is an int64 label vector [B]
+    (nn.CrossEntropyLoss, reference model_trainer.py:91) or a float [B,C] soft-target matrix (timm's
+    SoftTargetCrossEntropy after Mixup, :87-88).  fp32 logits."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = _chk(logits.float())
+        ops.need_cuda(target)
+        B, Cn = logits.shape
+        soft = target.is_floating_point()
+        if soft:
+            if tuple(target.shape) != (B, Cn):
+                raise ValueError(f'soft targets must be [{B}, {Cn}], got {tuple(target.shape)}')
+            target = target.float().contiguous()
+        else:
+            if tuple(target.shape) != (B,):
+                raise ValueError(f'labels must be [{B}], got {tuple(target.shape)}')
+            target = target.long().contiguous()
+        rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(B, dtype=torch.float32, device=logits.device)
+        mean = torch.empty((), dtype=torch.float32, device=logits.device)
+        ops.call('vtx_softmax_xent_fwd', ops.ptr(logits), ops.ptr(target) if soft else None, None if soft else ops.ptr(target),
+                 B, Cn, ops.ptr(rows), ops.ptr(lse), ops.ptr(mean), ops.stream())
+        ctx.save_for_backward(logits, target, lse)
+        ctx.soft = soft
+        return mean
+
+    @staticmethod
+    def backward(ctx, gloss):
+        logits, target, lse = ctx.saved_tensors
+        B, Cn = logits.shape
+        d = torch.empty_like(logits)
+        gloss = gloss.float().contiguous()          # stays on the device: no host sync inside backward
+        ops.call('vtx_softmax_xent_bwd', ops.ptr(logits), ops.ptr(target) if ctx.soft else None,
+                 None if ctx.soft else ops.ptr(target), ops.ptr(lse), B, Cn, 1.0 / B, ops.ptr(gloss), ops.ptr(d), ops.stream())
+        return d, None

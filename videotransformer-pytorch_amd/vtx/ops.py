@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import RowMap, IDENT, GemmDesc, GemmTnDesc, AttnDesc, AttnBwdDesc, call
+from ._lib import RowMap, IDENT, GemmDesc, GemmTnDesc, AttnDesc, AttnBwdDesc, call  # noqa: F401
 
 _DT = {torch.float32: _lib.VTX_F32, torch.bfloat16: _lib.VTX_BF16}
 
@@ -445,3 +445,49 @@ def hog_fwd(frames, want_bins=False):
     with _timed('hog', nbytes=frames.numel() + out.numel() * 8, key=f'{F}x{H}x{W}'):
         call('vtx_hog_fwd', ptr(frames), F, H, W, ptr(table), ptr(out), ptr(bins), stream())
     return (out, bins) if want_bins else out
+
+
+# ------------------------------------------------- clip-batch mixing, accuracy (csrc/head.hip)
+def mixup_batch_(x, lam):
+    """In place: x[b] = x[b]*lam + x[B-1-b]*(1-lam) on a contiguous fp32 [B, ...] batch (reference mixup.py:112-113)."""
+    need_cuda(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError('mixup_batch_: contiguous float32 batch required')
+    import numpy as np
+    B = x.shape[0]
+    # ATen multiplies a float32 tensor by a Python scalar after casting the scalar to float32
+    call('vtx_mixup_batch', ptr(x), B, x.numel() // B, float(np.float32(lam)), float(np.float32(1. - lam)), stream())
+    return x
+
+
+def cutmix_batch_(x, yl, yh, xl, xh):
+    """In place: x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh] on a contiguous fp32 [B, planes, H, W] batch."""
+    need_cuda(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.ndim != 4:
+        raise TypeError('cutmix_batch_: contiguous float32 [B, planes, H, W] batch required')
+    B, Pn, H, W = x.shape
+    call('vtx_cutmix_batch', ptr(x), B, Pn, H, W, int(yl), int(yh), int(xl), int(xh), stream())
+    return x
+
+
+def mixup_target(labels, num_classes, lam, smoothing):
+    """Label-smoothed one-hot rows mixed with the flipped batch's (reference mixup.py:20-25) -> fp32 [B, num_classes]."""
+    import numpy as np
+    need_cuda(labels)
+    labels = labels.long().contiguous().view(-1)
+    B = labels.numel()
+    off = smoothing / num_classes
+    on = 1. - smoothing + off
+    out = torch.empty(B, num_classes, dtype=torch.float32, device=labels.device)
+    call('vtx_mixup_target', ptr(labels), B, int(num_classes), float(np.float32(on)), float(np.float32(off)),
+         float(np.float32(lam)), float(np.float32(1. - lam)), ptr(out), stream())
+    return out
+
+
+def topk_correct(scores, labels, k, counter):
+    """counter (int32 device scalar) += rows of fp32 ``scores`` [B,C] whose label ranks among the k largest."""
+    need_cuda(scores, labels, counter)
+    scores = scores.float().contiguous()
+    labels = labels.long().contiguous()
+    B, Cn = scores.shape
+    call('vtx_topk_correct', ptr(scores), ptr(labels), B, Cn, int(k), ptr(counter), stream())
