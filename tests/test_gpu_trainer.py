@@ -62,8 +62,9 @@ def test_one_lightning_step(mix, optim_type):
         moved = sum(1 for k, v in m.named_parameters() if v.grad is not None and not torch.equal(v.detach(), before[k]))
         assert moved == sum(1 for v in m.parameters() if v.grad is not None) > 200
         assert 0.0 <= float(m.logged['top5_acc']) <= 1.0
-        # the clip bounds every parameter's update: |delta p| <= lr * (wd |p| + clip-limited gradient terms)
+        # epoch-wise warm-up of the reference's cosine schedule: lr = base * (epoch + 1) / warmup_epochs
+        assert abs(opt.param_groups[0]['lr'] - 0.025) < 1e-12
         scheds[0].step()
-        assert opt.param_groups[0]['lr'] != 0.05
+        assert abs(opt.param_groups[0]['lr'] - 0.05) < 1e-12
     finally:
         vtx.set_precision('auto')
