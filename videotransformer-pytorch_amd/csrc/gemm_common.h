@@ -18,7 +18,41 @@ struct EpiParams {
   const float* row_scale; int rs_d1, rs_m1, rs_d2, rs_m2;
   const void* R; long ldr; vtx_rowmap rmap; int r_period;
   int split_row; void* Csplit; long ldsplit;
+  unsigned rs_magic1, rs_shift1, rs_magic2, rs_shift2;   // fast_div constants of rs_d1 / rs_d2 (persistent kernel)
 };
+
+// Division of n < 2^31 by a launch constant d >= 1 without the ~25-instruction VALU sequence:
+// q = umulhi(n, magic) >> shift with magic = floor(2^(31+s) / d) + 1, s = ceil(log2 d), shift = s - 1 (d = 1: magic 0).
+struct FastDiv { unsigned magic, shift; };
+inline FastDiv make_fast_div(unsigned d) {
+  FastDiv f;
+  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.magic = (unsigned)(((1ull << (31 + s)) / d) + 1);
+  f.shift = s - 1;
+  return f;
+}
+__device__ inline unsigned fast_div(unsigned n, unsigned magic, unsigned shift) {
+  return magic ? (__umulhi(n, magic) >> shift) : n;
+}
+
+// Row map restricted to one 256-row tile (first row wave-uniform): the group quotient changes at most once
+// inside the tile when grp >= 256, so a row costs a compare and an add instead of a division.
+struct TileMap { int grp, skip; long base_q; int bound; bool fast; };
+__device__ inline TileMap make_tile_map(const vtx_rowmap& m, int first_row) {
+  TileMap t;
+  t.grp = m.grp; t.skip = m.skip;
+  t.fast = m.grp <= 0 || m.grp >= 256;
+  const unsigned q0 = m.grp > 0 ? (unsigned)first_row / (unsigned)m.grp : 0u;
+  t.base_q = (long)m.base + (long)q0 * (long)m.skip;
+  t.bound = m.grp > 0 ? (int)((q0 + 1) * (unsigned)m.grp) : 0x7fffffff;
+  return t;
+}
+__device__ inline long tile_map_row(const TileMap& t, const vtx_rowmap& m, int r) {     // r in [first_row, first_row + 256)
+  if (t.fast) return t.base_q + r + (r >= t.bound ? (long)t.skip : 0L);
+  return map_row(m, r);
+}
 
 // XCD-aware bijective remap of the linear block id (8 XCDs, block b runs on XCD b%8):
 // gives every XCD a contiguous run of logical tiles so neighbouring tiles share L2.

@@ -374,7 +374,7 @@ template <bool EPI2, bool HAS_PRE, bool HAS_SC>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, int* __restrict__ tile_ctr,
-    long long* __restrict__ trace, EpiParams ep) {
+    long long* __restrict__ trace, int dbg, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -460,18 +460,19 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     const int rr = r / wg, cc = r - rr * wg;
     const int tm = rlo + rr, tn = g * CG + cc;
     m0 = tm * PP_BM; n0 = tn * PP_BN;
+    const TileMap am = make_tile_map(amap, m0);
+    const int m_last = M - 1;
+    const long a_last = map_row(amap, m_last);   // clamp target of rows beyond M (ragged last tile only)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                // this wave owns pieces 2*wave, 2*wave+1 (8 region rows each)
       const int rho = (wave * 2 + j) * 8 + (lane >> 3);
       const int c = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
-      int ma0 = m0 + (rho >> 6) * 128 + (rho & 63), ma1 = ma0 + 64;
-      if (ma0 >= M) ma0 = M - 1;
-      if (ma1 >= M) ma1 = M - 1;
+      const int ma0 = m0 + (rho >> 6) * 128 + (rho & 63), ma1 = ma0 + 64;
       int nb0 = n0 + (rho >> 5) * 64 + (rho & 31), nb1 = nb0 + 32;
       if (nb0 >= N) nb0 = N - 1;
       if (nb1 >= N) nb1 = N - 1;
-      src[0][j] = A + map_row(amap, ma0) * lda + c;
-      src[3][j] = A + map_row(amap, ma1) * lda + c;
+      src[0][j] = A + (ma0 > m_last ? a_last : tile_map_row(am, amap, ma0)) * lda + c;
+      src[3][j] = A + (ma1 > m_last ? a_last : tile_map_row(am, amap, ma1)) * lda + c;
       src[1][j] = B + (long)nb0 * ldb + c;
       src[2][j] = B + (long)nb1 * ldb + c;
     }
@@ -613,17 +614,21 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       const int er = em0 + (lane >> 3);            // row of pass p, half-row u: er + 16 p + 8 u
       const bool pre_res = ep.R != nullptr;
       bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: lane-linear per piece
+      const int tile_m0 = em0 - wr * 128;          // first row of the whole 256-row tile (wave-uniform)
       if constexpr (HAS_PRE) {
         const bf16raw* const pre_base = reinterpret_cast<const bf16raw*>(pre_res ? ep.R : ep.dgelu_in);
         const long pre_ld = pre_res ? ep.ldr : ep.ld_dgelu;
+        const TileMap rm = make_tile_map(ep.rmap, tile_m0);
+        const int row_last = ep.M - 1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {             // piece j = rows 8j .. 8j+7 of the block; lane -> row 8j + lane/8, chunk lane%8
           int ml = er + 8 * j;
-          if (ml >= ep.M) ml = ep.M - 1;           // always-valid addresses; only the stores are predicated
+          const bool past = ml > row_last;         // always-valid addresses; only the stores are predicated
+          if (past) ml = row_last;
           long rr = ml;
           if (pre_res) {
             const bool split = ep.split_row > 0 && ml >= ep.split_row;      // split rows take no residual: read row 0
-            rr = split ? 0 : (ep.r_period > 0 ? (long)(ml % ep.r_period) : map_row(ep.rmap, ml));
+            rr = split ? 0 : (ep.r_period > 0 ? (long)(ml % ep.r_period) : (past ? map_row(ep.rmap, ml) : tile_map_row(rm, ep.rmap, ml)));
           }
           dma16(pre_base + rr * pre_ld + enc, pre_lds + j * 512);
         }
@@ -647,7 +652,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
             int ml = er + 16 * p + 8 * u;
             if (ml >= ep.M) ml = ep.M - 1;
             const bool split = ep.split_row > 0 && ml >= ep.split_row;
-            sc[p][u] = ep.row_scale[split ? (ml - ep.split_row) : (ml / ep.rs_d1) * ep.rs_m1 + (ml % ep.rs_d2) * ep.rs_m2];
+            const unsigned q1 = fast_div((unsigned)ml, ep.rs_magic1, ep.rs_shift1);
+            const unsigned q2 = fast_div((unsigned)ml, ep.rs_magic2, ep.rs_shift2);
+            sc[p][u] = ep.row_scale[split ? (ml - ep.split_row) : (int)q1 * ep.rs_m1 + (ml - (int)q2 * ep.rs_d2) * ep.rs_m2];
           }
       }
       if (more && tid == 0) pending = atomicAdd(my_ctr, 1);
@@ -665,6 +672,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         if (more) { set_tile(t); prologue(); }      // ring is free: the next tile's first 7 regions land under the passes
       }
       stamp(5);
+      const TileMap cm = make_tile_map(ep.cmap, tile_m0);
       // The staged rows (and the residual rows) are read back with inline-asm ds_read + lgkmcnt(0) in ONE statement:
       // hipcc orders any ds_read IT emits behind every LDS-DMA in flight (`s_waitcnt vmcnt(0)`), i.e. pass 0 would
       // wait for the 14 prologue requests issued just above.
@@ -675,8 +683,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #define PP_EPI2(p_, mi_, half_)                                                                         \
       {                                                                                                 \
         const int col = lane & 31, rhalf = (lane >> 5) * 4;                                             \
+        if (dbg != 3) {                                                                                 \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)  \
             stg[((r & 3) + 8 * (r >> 2) + rhalf) * PP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r] + bcol[ni]; \
+        } else { stg[lane] = acc[mi_][0][8 * (half_)] + acc[mi_][1][8 * (half_) + 7]; }                 \
         lgkm0();                                                                                        \
         __builtin_amdgcn_wave_barrier();                                                                \
         f32x4 s00, s01, s10, s11;                                                                       \
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         }                                                                                               \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
           const int m = er + 16 * (p_) + 8 * u;                                                         \
-          const bool ok = col_ok && m < ep.M;                                                           \
+          const bool ok = col_ok && m < ep.M && dbg != 2;                                               \
           const bool split = ep.split_row > 0 && m >= ep.split_row;                                     \
           if (ep.act == 1) {                                                                            \
             if (ep.C2 && ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, v[u]);  \
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           }                                                                                             \
           if (ok) {                                                                                     \
             if (split) store8(reinterpret_cast<bf16raw*>(ep.Csplit) + (long)(m - ep.split_row) * ep.ldsplit + en, v[u]); \
-            else store8(reinterpret_cast<bf16raw*>(ep.C) + map_row(ep.cmap, m) * ep.ldc + en, v[u]);    \
+            else store8(reinterpret_cast<bf16raw*>(ep.C) + tile_map_row(cm, ep.cmap, m) * ep.ldc + en, v[u]); \
           }                                                                                             \
         }                                                                                               \
       }
@@ -766,7 +776,7 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   if (cg < 1) cg = 1;
   hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
                      (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg,
-                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, ep);
+                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, ep);
   return check_launch("gemm_nt_pp");
 }
 
@@ -912,6 +922,10 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
   ep.row_scale = d->row_scale; ep.rs_d1 = d->rs_d1; ep.rs_m1 = d->rs_m1; ep.rs_d2 = d->rs_d2; ep.rs_m2 = d->rs_m2;
   ep.R = d->R; ep.ldr = d->ldr; ep.rmap = d->rmap; ep.r_period = d->r_period;
   ep.split_row = d->split_row; ep.Csplit = d->Csplit; ep.ldsplit = d->ldsplit;
+  {
+    const FastDiv f1 = make_fast_div(d->row_scale ? (unsigned)d->rs_d1 : 1u), f2 = make_fast_div(d->row_scale ? (unsigned)d->rs_d2 : 1u);
+    ep.rs_magic1 = f1.magic; ep.rs_shift1 = f1.shift; ep.rs_magic2 = f2.magic; ep.rs_shift2 = f2.shift;
+  }
 
   const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
   dim3 grid(tiles_m * tiles_n), block(NT_THREADS);
