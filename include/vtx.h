@@ -187,6 +187,9 @@ int vtx_row_scale_copy(int dtype, int rows, int D, const void* src, long lds, vt
 /* out[j,:] (+)= scale * sum_{i<ni} in[base + i*si + j*sj, :]   (fp32 out).  in_dtype: VTX_F32/BF16. */
 int vtx_reduce_rows(int in_dtype, int nj, int ni, int D, const void* in, long ld, long base,
                     long si, long sj, float* out, long ldo, float scale, int accumulate, void* stream);
+/* out = dy * gelu'(h), n elements (n % 8 == 0): backward of an erf-GELU whose gradient does not come out of a
+ * GEMM epilogue (MViT Mlp, video_transformer.py:763-786 via pytorchvideo). */
+int vtx_gelu_grad_mul(int dtype, size_t n, const void* dy, const void* h, void* out, void* stream);
 /* Weight staging: W fp32 [R,C] -> Wc (dtype, [R,C], optional) and WcT (dtype, [C,R], optional). */
 int vtx_cast_transpose(int dtype, int R, int C, const float* W, void* Wc, void* WcT, void* stream);
 /* dst (dtype) = src (fp32), n elements; and the reverse. */
@@ -249,6 +252,44 @@ int vtx_maskfeat_loss_fwd(int dtype, int B, int Tq, int ts, int g, int Cf, const
 int vtx_maskfeat_loss_bwd(int dtype, int B, int Tq, int ts, int g, int Cf, const void* pred, long ldp,
                           const double* target, const uint8_t* cmask, const double* loss_out,
                           float gloss, void* dpred, long lddp, void* stream);
+
+/* ------------------------------------------------------------------ MViT backbone operators
+ * The operators of the MViT-B backbone of MaskFeat that the blocks above do not cover (the reference
+ * builds it from pytorchvideo: video_transformer.py:621-800; semantics restated in oracle/mvit_oracle.py).
+ * Token tensors are [B, 1 + T*H*W, heads*hd] (cls first, heads interleaved in the feature axis), head_dim 64 or 96.
+ *
+ * Pooling of q / k / v (MultiScaleAttention): per-head depthwise Conv3d(3x3x3, stride (1,sh,sw), padding 1, no
+ * bias; w [hd,27] = the [hd,1,3,3,3] weight) on the non-cls tokens + LayerNorm(hd) on every token (cls included).
+ * Output grid H' = (H - 1) / sh + 1.  fwd saves `pre` (conv output, before the norm) and mean / rstd [B*(1+N')*heads]. */
+typedef struct { int dtype, B, T, H, W, heads, hd, sh, sw; } vtx_pool_desc;
+int vtx_pool_conv_ln_fwd(const vtx_pool_desc* d, const void* x, const float* w, const float* gamma, const float* beta,
+                         float eps, void* pre, void* y, float* mean, float* rstd, void* stream);
+size_t vtx_pool_conv_ln_bwd_workspace(const vtx_pool_desc* d);
+/* dpre: scratch of the output's shape; dx of the input's; dw [hd,27], dgamma / dbeta [hd] are overwritten. */
+int vtx_pool_conv_ln_bwd(const vtx_pool_desc* d, const void* dy, const void* x, const void* pre, const float* mean,
+                         const float* rstd, const float* w, const float* gamma, void* dpre, void* dx, float* dw,
+                         float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+/* Residual-path MaxPool3d(kernel (1,3,3), stride (1,2,2), padding (0,1,1)), cls row kept; arg [B,1+N',C] uint8. */
+int vtx_maxpool_skip_fwd(int dtype, int B, int T, int H, int W, int C, const void* x, void* y, uint8_t* arg, void* stream);
+int vtx_maxpool_skip_bwd(int dtype, int B, int T, int H, int W, int C, const void* dy, const uint8_t* arg, void* dx, void* stream);
+/* Separable position encoding + cls token: out [B,1+T*HW,C] from x [B,T*HW,C]; cls, pos_class [C], spatial [HW,C],
+ * temporal [T,C] fp32. */
+int vtx_pos_encoding_fwd(int dtype, int B, int T, int HW, int C, const void* x, const float* cls, const float* pos_class,
+                         const float* spatial, const float* temporal, void* out, void* stream);
+/* Rows of an overlapping, padded Conv3d on the clip [B,T,C,H,W] fp32: rows[(b,to,ho,wo)][c*kt*kh*kw + ...] (weight
+ * order), zero padded to Kp columns; k3 / s3 / p3 = HOST (t,h,w) kernel / stride / padding triples. */
+int vtx_im2col3d(int dtype, int B, int T, int C, int H, int W, const int* k3, const int* s3, const int* p3, int Kp,
+                 const float* clip, void* rows, void* stream);
+/* softmax(q k^T * scale) v with separate q [B,Lq,heads*hd] and k, v [B,Lk,heads*hd]; lse [B,heads,Lq] fp32.
+ * bwd: delta [B,heads,Lq] fp32 scratch. */
+typedef struct {
+  int dtype, B, Lq, Lk, heads, hd;
+  float scale;
+  const void* q; const void* k; const void* v;
+  void* out; float* lse;
+} vtx_xattn_desc;
+int vtx_xattn_fwd(const vtx_xattn_desc* d, void* stream);
+int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, void* dk, void* dv, void* stream);
 
 /* ------------------------------------------- clip-batch mixing, classification loss, accuracy
  * Mixup / CutMix of the clip batch in place (mixup.py:102-126; the numpy draws stay on the host): x is

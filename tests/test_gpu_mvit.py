@@ -1,0 +1,247 @@
+"""MViT-B backbone (mvit.py + csrc/mvit.hip) against the CPU restatement oracle/mvit_oracle.py: every new operator
+on small grids, a reduced backbone with all gradients, and MaskFeat end to end exactly as the reference's trainer
+constructs it (model_trainer.py:53-54).  PARITY UNPINNED BY THE REFERENCE: pytorchvideo, which holds this arithmetic
+in the reference, is on no disk of this build -- the oracle is a restatement from the paper / the 0.1.3 sources."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_BF16, TOL_F32, check
+from oracle import mvit_oracle as MO
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def q(t, dtype):
+    return t.to(dtype).double()
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('hd,heads,stride,thw', [(96, 2, (1, 2, 2), (2, 8, 8)), (96, 1, (1, 8, 8), (2, 16, 16)),
+                                                 (64, 3, (1, 4, 4), (3, 8, 12)), (96, 4, (1, 1, 1), (2, 5, 7))])
+def test_pool_conv_ln(dtype, hd, heads, stride, thw):
+    from vtx import functions as F_
+    B, C = 2, heads * hd
+    T, H, W = thw
+    x = rnd(B, 1 + T * H * W, C, seed=1)
+    conv = torch.nn.Conv3d(hd, hd, 3, stride=stride, padding=1, groups=hd, bias=False).double()
+    norm = torch.nn.LayerNorm(hd).double()
+    with torch.no_grad():
+        conv.weight.copy_(rnd(hd, 1, 3, 3, 3, seed=2) * 0.3)
+        norm.weight.copy_(1 + 0.1 * rnd(hd, seed=3))
+        norm.bias.copy_(0.1 * rnd(hd, seed=4))
+    xr = q(x, dtype).requires_grad_(True)
+    t4 = xr.reshape(B, 1 + T * H * W, heads, hd).permute(0, 2, 1, 3)
+    ref, thw2 = MO.attention_pool(t4, conv, list(thw), norm)
+    ref = ref.permute(0, 2, 1, 3).reshape(B, -1, C)
+    dy = rnd(*ref.shape, seed=5)
+    ref.backward(q(dy, dtype))
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    cw = conv.weight.detach().float().to(DEV).requires_grad_(True)
+    gw = norm.weight.detach().float().to(DEV).requires_grad_(True)
+    gb = norm.bias.detach().float().to(DEV).requires_grad_(True)
+    y = F_.PoolConvLNFn.apply(xg, cw, gw, gb, list(thw), heads, stride, norm.eps)
+    assert F_.pooled_thw(list(thw), stride) == thw2
+    y.backward(dy.to(DEV).to(dtype))
+    tag = f'pool {dtype} hd={hd} s={stride}'
+    check(f'{tag} y', y.float().cpu(), ref.detach(), TOL[dtype])
+    check(f'{tag} dx', xg.grad.float().cpu(), xr.grad, 2 * TOL[dtype])
+    check(f'{tag} dw', cw.grad.cpu(), conv.weight.grad, 2 * TOL[dtype])
+    check(f'{tag} dgamma', gw.grad.cpu(), norm.weight.grad, 2 * TOL[dtype])
+    check(f'{tag} dbeta', gb.grad.cpu(), norm.bias.grad, 2 * TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('thw', [(2, 8, 8), (3, 7, 9)])
+def test_maxpool_skip(dtype, thw):
+    from vtx import functions as F_
+    B, C = 2, 40
+    T, H, W = thw
+    x = rnd(B, 1 + T * H * W, C, seed=1)
+    xr = q(x, dtype).requires_grad_(True)
+    pool = torch.nn.MaxPool3d([1, 3, 3], [1, 2, 2], [0, 1, 1])
+    ref, _ = MO.attention_pool(xr, pool, list(thw))
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(q(dy, dtype))
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    y = F_.MaxPoolSkipFn.apply(xg, list(thw))
+    y.backward(dy.to(DEV).to(dtype))
+    assert torch.equal(y.float().cpu().double(), ref.detach()), 'max pooling is exact'
+    check(f'maxpool {dtype} dx', xg.grad.float().cpu(), xr.grad, 1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('hd,heads,Lq,Lk', [(96, 2, 130, 37), (96, 1, 300, 393), (64, 3, 33, 200)])
+def test_cross_attention(dtype, hd, heads, Lq, Lk):
+    from vtx import functions as F_
+    B, C = 2, heads * hd
+    qq, kk, vv = rnd(B, Lq, C, seed=1), rnd(B, Lk, C, seed=2), rnd(B, Lk, C, seed=3)
+    ref_in = [q(t, dtype).requires_grad_(True) for t in (qq, kk, vv)]
+    sp = lambda t, L: t.reshape(B, L, heads, hd).permute(0, 2, 1, 3)   # noqa: E731
+    att = ((sp(ref_in[0], Lq) @ sp(ref_in[1], Lk).transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (att @ sp(ref_in[2], Lk)).transpose(1, 2).reshape(B, Lq, C)
+    do = rnd(B, Lq, C, seed=4)
+    ref.backward(q(do, dtype))
+    g = [t.to(DEV).to(dtype).requires_grad_(True) for t in (qq, kk, vv)]
+    o = F_.XAttnFn.apply(g[0], g[1], g[2], heads)
+    o.backward(do.to(DEV).to(dtype))
+    tag = f'xattn {dtype} hd={hd} {Lq}x{Lk}'
+    check(f'{tag} out', o.float().cpu(), ref.detach(), TOL[dtype])
+    for name, a, b in zip('qkv', g, ref_in):
+        check(f'{tag} d{name}', a.grad.float().cpu(), b.grad, 2 * TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_pos_encoding_and_stem(dtype):
+    from vtx import functions as F_
+    B, T, H, W, C = 2, 2, 4, 4, 96
+    enc = MO.SpatioTemporalClsPositionalEncoding(C, [T, H, W]).double()
+    with torch.no_grad():
+        for i, p in enumerate(enc.parameters()):
+            p.copy_(rnd(*p.shape, seed=10 + i))
+    x = rnd(B, T * H * W, C, seed=1)
+    xr = q(x, dtype).requires_grad_(True)
+    ref = enc(xr)
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(q(dy, dtype))
+    ps = [p.detach().float().to(DEV).requires_grad_(True) for p in (enc.cls_token, enc.pos_embed_class, enc.pos_embed_spatial,
+                                                                      enc.pos_embed_temporal)]
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    y = F_.PosEncodingFn.apply(xg, *ps)
+    y.backward(dy.to(DEV).to(dtype))
+    check(f'pos enc {dtype}', y.float().cpu(), ref.detach(), TOL[dtype])
+    check(f'pos enc dx {dtype}', xg.grad.float().cpu(), xr.grad, TOL[dtype])
+    for name, a, b in zip(('cls', 'class', 'spatial', 'temporal'), ps, (enc.cls_token, enc.pos_embed_class,
+                                                                         enc.pos_embed_spatial, enc.pos_embed_temporal)):
+        check(f'pos enc d{name} {dtype}', a.grad.cpu(), b.grad, 2 * TOL[dtype])
+    # stem: Conv3d(3 -> 96, (3,7,7), stride (2,4,4), padding (1,3,3)) on a [B,T,C,H,W] clip
+    conv = torch.nn.Conv3d(3, 96, (3, 7, 7), stride=(2, 4, 4), padding=(1, 3, 3)).double()
+    clip = rnd(2, 4, 3, 16, 24, seed=3)
+    wq = q(conv.weight.detach().float(), dtype)
+    refs = torch.nn.functional.conv3d(q(clip, dtype).transpose(1, 2), wq, conv.bias, stride=(2, 4, 4), padding=(1, 3, 3))
+    refs = refs.flatten(2).transpose(1, 2)
+    cw = conv.weight.detach().float().to(DEV).requires_grad_(True)
+    cb = conv.bias.detach().float().to(DEV).requires_grad_(True)
+    ys = F_.ConvStemFn.apply(clip.to(DEV), cw, cb, (2, 4, 4), (1, 3, 3), dtype)
+    check(f'conv stem {dtype}', ys.float().cpu(), refs.detach(), TOL[dtype])
+    dy = rnd(*ys.shape, seed=4)
+    ys.backward(dy.to(DEV).to(dtype))
+    conv.zero_grad()
+    wr = conv.weight.detach().clone().requires_grad_(True)
+    out = torch.nn.functional.conv3d(q(clip, dtype).transpose(1, 2), wr, conv.bias, stride=(2, 4, 4), padding=(1, 3, 3))
+    out.flatten(2).transpose(1, 2).backward(q(dy, dtype))
+    check(f'conv stem dw {dtype}', cw.grad.cpu(), wr.grad, 2 * TOL[dtype])
+
+
+def _share(ours, oracle, seed):
+    sd = synth.synth_state_dict(synth.shapes_of(oracle), seed)
+    for k in list(sd):                              # depthwise pooling kernels: fan-in 27, keep them O(1)
+        if 'pool_' in k:
+            sd[k] = sd[k] * 3.0
+        if 'pos_embed' in k:
+            sd[k] = synth.synth_tensor(k, tuple(sd[k].shape), seed) * 0.02
+    oracle.load_state_dict(sd, strict=True)
+    missing, unexpected = ours.load_state_dict(sd, strict=True), None
+    return sd
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', 2 * TOL_BF16)])
+def test_reduced_mvit_all_gradients(prec, tol):
+    """A 5-block MViT (two Q-pooling stages, adaptive K/V strides, widening, head doubling) on a 4x32x32 token grid:
+    outputs and every parameter gradient against the oracle with shared weights."""
+    import vtx
+    import mvit
+    vtx.set_precision(prec)
+    try:
+        kw = dict(depth=5, patch_embed_dim=96, num_heads=1, embed_dim_mul=[[1, 2.0], [3, 2.0]], atten_head_mul=[[1, 2.0], [3, 2.0]],
+                  pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]], pool_kv_stride_adaptive=[1, 4, 4], pool_kvq_kernel=[3, 3, 3])
+        ours = mvit.create_multiscale_vision_transformers(spatial_size=128, temporal_size=8, **kw)
+        oracle = MO.MultiscaleVisionTransformers(spatial_size=128, temporal_size=8, **kw)
+        _share(ours, oracle, 5)
+        ours.to(DEV)
+        x = rnd(2, 4 * 32 * 32, 96, seed=7)
+        yo = oracle(x)
+        w = rnd(*yo.shape, seed=8)
+        (yo * w).sum().backward()
+        y = ours(x.to(DEV))
+        (y * w.to(DEV)).sum().backward()
+        assert y.dtype == torch.float32 and y.shape == yo.shape
+        check(f'reduced MViT {prec} out', y.cpu(), yo.detach(), tol)
+        go = dict(oracle.named_parameters())
+        worst = 0.0
+        for k, p in ours.named_parameters():
+            ref = go[k].grad
+            e = (p.grad.cpu().double() - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-30)
+            worst = max(worst, e)
+            assert e <= (1e-3 if prec == 'fp32' else 6e-2), (k, e)
+        from helpers import report
+        report(f'ok   reduced MViT {prec}: {len(go)} parameter gradients, worst l2-rel={worst:.3e}')
+    finally:
+        vtx.set_precision('auto')
+
+
+def test_maskfeat_as_the_reference_trainer_builds_it():
+    """MaskFeat(pool_q_stride_size=[[1,1,2,2],[3,1,2,2]], feature_dim=216) -- model_trainer.py:53-54 -- on one 16x224^2
+    clip: MViT-B (16 blocks, 36.3 M parameters, 25 089 -> 6 273 -> 1 569 tokens), decoder, HOG-target masked MSE; loss and
+    gradients against the oracle backbone + the reference's head arithmetic on the CPU."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision('fp32')
+    try:
+        torch.manual_seed(0)
+        m = V.MaskFeat(pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]], feature_dim=2 * 2 * 2 * 3 * 9)
+        assert m.embed_dims == 768 and m.downsample_rate == 4
+        oracle = MO.MultiscaleVisionTransformers(embed_dim_mul=[[1, 2.0], [3, 2.0], [14, 2.0]],
+                                                 atten_head_mul=[[1, 2.0], [3, 2.0], [14, 2.0]],
+                                                 pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]], pool_kv_stride_adaptive=[1, 8, 8],
+                                                 pool_kvq_kernel=[3, 3, 3])
+        assert sorted(k for k in m.mvit.state_dict()) == sorted(oracle.state_dict())
+        assert abs(sum(p.numel() for p in m.mvit.parameters()) - 36.26e6) < 0.05e6
+        _share(m.mvit, oracle, 9)
+        m.to(DEV)
+        B = 1
+        x = synth.synth_clip(B, 16, seed=8)
+        g = torch.Generator().manual_seed(99)
+        target = torch.rand(B, 16, 14, 14, 108, generator=g, dtype=torch.float64)
+        mask = torch.zeros(B, 8, 14, 14, dtype=torch.int32)
+        mask[0, 2:4, 3:9, 2:10] = 1
+        mask[0, 6, 5:12, 5:12] = 1
+        markers = [[[2, 2], [6, 1]]]
+        pred, loss = m(x.to(DEV), target.to(DEV), mask.to(DEV), markers)
+        loss.backward()
+        # ---- CPU: the same computation with torch ops (reference video_transformer.py:876-922) on the oracle backbone
+        pm = m.patch_embed.patch_model
+        tok = torch.nn.functional.conv3d(x.transpose(1, 2), pm.weight.detach().cpu(), pm.bias.detach().cpu(), stride=(2, 4, 4),
+                                         padding=(1, 3, 3)).flatten(2).transpose(1, 2)
+        wmask = mask.repeat_interleave(4, 2).repeat_interleave(4, 3).flatten(1).unsqueeze(-1).float()
+        tok = tok * (1 - wmask) + m.mask_token.detach().cpu() * wmask
+        feat = oracle(tok)
+        dec_w = m.decoder_pred.weight.detach().cpu().clone().requires_grad_(True)
+        p = (feat @ dec_w.t() + m.decoder_pred.bias.detach().cpu())[:, 1:]
+        p = p.reshape(B, 8, 14, 14, 2, 108).permute(0, 1, 4, 2, 3, 5).reshape(B, 16, 14, 14, 108)
+        mk = mask.repeat_interleave(2, 1).clone()
+        keep = torch.zeros(16, dtype=torch.bool)
+        for s, span in markers[0]:
+            keep[s * 2 + span * 2 // 2] = True
+        mk[0, ~keep] = 0
+        ref_loss = (((p - target) ** 2).mean(-1) * mk).sum() / (mk.sum() + 1e-5)
+        ref_loss.backward()
+        check('MaskFeat/MViT-B pred', pred.cpu(), p.detach(), 1e-3)
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+        check('MaskFeat/MViT-B d decoder', m.decoder_pred.weight.grad.cpu(), dec_w.grad, 1e-3)
+        go = dict(oracle.named_parameters())
+        for k in ('blocks.0.attn.pool_k.weight', 'blocks.1.attn.pool_q.weight', 'blocks.3.attn.q.weight', 'blocks.13.proj.weight',
+                  'cls_positional_encoding.pos_embed_spatial', 'blocks.15.mlp.fc2.bias', 'blocks.0.norm1.weight'):
+            a, b = dict(m.mvit.named_parameters())[k].grad.cpu().double(), go[k].grad.double()
+            e = (a - b).norm().item() / max(b.norm().item(), 1e-30)
+            assert e < 1e-3, (k, e)
+    finally:
+        vtx.set_precision('auto')

@@ -275,6 +275,35 @@ using namespace vtx;
   else if ((dtype) == VTX_BF16) { CALL_BF16; }                    \
   else VTX_REQUIRE(false, VTX_EINVAL, name ": bad dtype %d", (int)(dtype))
 
+// out = dy * gelu'(h)  (backward of a GELU whose consumer is not a GEMM epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_grad_mul_kernel(size_t n8, const T* __restrict__ dy, const T* __restrict__ h, T* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float a[8], b[8];
+    load8(dy + i * 8, a);
+    load8(h + i * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] *= gelu_erf_grad(b[j]);
+    store8(out + i * 8, a);
+  }
+}
+
+extern "C" int vtx_gelu_grad_mul(int dtype, size_t n, const void* dy, const void* h, void* out, void* stream) {
+  VTX_REQUIRE(n % 8 == 0 && dy && h && out && aligned16(dy) && aligned16(h) && aligned16(out), VTX_EINVAL,
+              "gelu_grad_mul: n must be a multiple of 8 and the pointers 16-byte aligned");
+  if (n == 0) return VTX_OK;
+  const size_t n8 = n / 8;
+  const int grid = (int)((n8 + 255) / 256 > 16384 ? 16384 : (n8 + 255) / 256);
+  hipStream_t st = as_stream(stream);
+  if (dtype == VTX_F32)
+    hipLaunchKernelGGL(gelu_grad_mul_kernel<float>, dim3(grid), dim3(256), 0, st, n8, (const float*)dy, (const float*)h, (float*)out);
+  else if (dtype == VTX_BF16)
+    hipLaunchKernelGGL(gelu_grad_mul_kernel<bf16raw>, dim3(grid), dim3(256), 0, st, n8, (const bf16raw*)dy, (const bf16raw*)h, (bf16raw*)out);
+  else
+    VTX_REQUIRE(false, VTX_EINVAL, "gelu_grad_mul: bad dtype %d", dtype);
+  return check_launch("gelu_grad_mul");
+}
+
 extern "C" int vtx_cast_transpose(int dtype, int R, int C, const float* W, void* Wc, void* WcT, void* stream) {
   VTX_REQUIRE(R > 0 && C > 0 && W && (Wc || WcT), VTX_EINVAL, "cast_transpose: bad arguments");
   dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);

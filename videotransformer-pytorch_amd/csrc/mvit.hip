@@ -1,0 +1,692 @@
+// mvit.hip -- the operators of the MViT-B backbone that the transformer kernels do not cover
+// (reference video_transformer.py:621-800 builds the backbone from
+// pytorchvideo -- semantics restated in oracle/mvit_oracle.py, parity unpinned by the reference):
+//
+//   pool_conv_ln   pooling of q / k / v inside MultiScaleAttention: per-head depthwise Conv3d(3x3x3, stride
+//                  (1,s,s), padding 1, no bias) over the [T,H,W] token grid + LayerNorm(head_dim); the cls token
+//                  bypasses the convolution but not the norm.  Tokens stay in [B, 1+T*H*W, heads*hd] layout
+//                  (heads interleaved in the feature axis): the conv weight of column c is w[c % hd].
+//   maxpool_skip   MaxPool3d(kernel (1,3,3), stride (1,2,2), padding (0,1,1)) on the residual path, cls kept.
+//   xattn          softmax(q k^T hd^-0.5) v with Lq != Lk (queries and keys pooled by different strides),
+//                  head_dim 96 (MViT-B) or 64; fp32 VALU arithmetic, K/V tiles in LDS, online softmax.
+//   pos_encoding   separable spatial + temporal position embedding and the cls token.
+//   im2col3d       rows of the overlapping Conv3d(3 -> 96, kernel (3,7,7), stride (2,4,4), padding (1,3,3)) stem.
+//
+// First-correct kernels: HBM/VALU bound, not tuned (the backbone is 70 GFLOP per clip against TimeSformer-B's 392).
+#include "common.h"
+
+namespace vtx {
+
+// ---------------------------------------------------------------------------------------------------
+// pool_conv_ln.  Half a wave (32 lanes) owns one (output token, head): lane l holds columns l, l+32, ... of the head.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void pool_conv_ln_fwd_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw, int heads,
+                                                               const T* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               T* __restrict__ pre, T* __restrict__ y, float* __restrict__ mean,
+                                                               float* __restrict__ rstd) {
+  constexpr int CPL = HD / 32;
+  const int C = heads * HD;
+  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
+  const long unit = (long)blockIdx.x * 8 + (threadIdx.x >> 5);          // (b, out token, head)
+  const int l = threadIdx.x & 31;
+  if (unit >= (long)B * n_out * heads) return;
+  const int hd_i = (int)(unit % heads);
+  const long bo = unit / heads;
+  const long o = bo % n_out;
+  const int b = (int)(bo / n_out);
+  const T* xb = x + (long)b * n_in * C + hd_i * HD;
+  float v[CPL];
+  if (o == 0) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) v[j] = ET<T>::ld(xb + l + 32 * j);
+  } else {
+    const long r = o - 1;
+    const int to = (int)(r / ((long)Ho * Wo)), ho = (int)((r / Wo) % Ho), wo = (int)(r % Wo);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) v[j] = 0.f;
+    for (int kt = 0; kt < 3; ++kt) {
+      const int t = to + kt - 1;
+      if (t < 0 || t >= Tn) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hh = ho * sh + kh - 1;
+        if (hh < 0 || hh >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ww = wo * sw + kw - 1;
+          if (ww < 0 || ww >= W) continue;
+          const T* xr = xb + (1 + ((long)t * H + hh) * W + ww) * C;
+          const int tap = (kt * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) v[j] = fmaf(w[(l + 32 * j) * 27 + tap], ET<T>::ld(xr + l + 32 * j), v[j]);
+        }
+      }
+    }
+  }
+  T* pr = pre + ((long)b * n_out + o) * C + hd_i * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    ET<T>::st(pr + l + 32 * j, v[j]);
+    v[j] = ET<T>::ld(pr + l + 32 * j);          // the LayerNorm sees the stored (rounded) value, as backward will
+    s += v[j];
+  }
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+  const float mu = s / HD;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) { const float d = v[j] - mu; q += d * d; }
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) q += __shfl_xor(q, m, 64);
+  const float rs = rsqrtf(q / HD + eps);
+  T* yr = y + ((long)b * n_out + o) * C + hd_i * HD;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) ET<T>::st(yr + l + 32 * j, (v[j] - mu) * rs * gamma[l + 32 * j] + beta[l + 32 * j]);
+  if (l == 0) { mean[unit] = mu; rstd[unit] = rs; }
+}
+
+// LayerNorm backward per (token, head): dpre, and per-block partial sums of dgamma / dbeta
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(long units, int heads, const T* __restrict__ dy, const T* __restrict__ pre,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, T* __restrict__ dpre, float* __restrict__ part) {
+  constexpr int CPL = HD / 32;
+  __shared__ float red[8][2][HD];
+  const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  float dg[CPL], db[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  for (long unit = (long)blockIdx.x * 8 + hw; unit < units; unit += (long)gridDim.x * 8) {
+    const long off = (unit / heads) * ((long)heads * HD) + (unit % heads) * HD;
+    const float mu = mean[unit], rs = rstd[unit];
+    float g[CPL], xh[CPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const float d = ET<T>::ld(dy + off + l + 32 * j);
+      xh[j] = (ET<T>::ld(pre + off + l + 32 * j) - mu) * rs;
+      g[j] = d * gamma[l + 32 * j];
+      s1 += g[j]; s2 += g[j] * xh[j];
+      dg[j] += d * xh[j]; db[j] += d;
+    }
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+    s1 /= HD; s2 /= HD;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) ET<T>::st(dpre + off + l + 32 * j, rs * (g[j] - s1 - xh[j] * s2));
+  }
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) { red[hw][0][l + 32 * j] = dg[j]; red[hw][1][l + 32 * j] = db[j]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * HD; i += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][i / HD][i % HD];
+    part[(long)blockIdx.x * 2 * HD + i] = a;
+  }
+}
+
+// dx of the depthwise conv (gather over the outputs whose window holds the input token); cls row passes through
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void pool_conv_bwd_data_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw, int C,
+                                                                 const T* __restrict__ dpre, const float* __restrict__ w,
+                                                                 T* __restrict__ dx) {
+  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
+  const long total = (long)B * n_in * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long bn = i / C;
+    const long n = bn % n_in;
+    const int b = (int)(bn / n_in);
+    const T* db = dpre + (long)b * n_out * C + c;
+    float a = 0.f;
+    if (n == 0) {
+      a = ET<T>::ld(db);
+    } else {
+      const long r = n - 1;
+      const int t = (int)(r / ((long)H * W)), h = (int)((r / W) % H), ww = (int)(r % W);
+      const float* wc = w + (c % HD) * 27;
+      for (int kt = 0; kt < 3; ++kt) {
+        const int to = t - kt + 1;
+        if (to < 0 || to >= Tn) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hn = h - kh + 1;
+          if (hn < 0 || hn % sh || hn / sh >= Ho) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int wn = ww - kw + 1;
+            if (wn < 0 || wn % sw || wn / sw >= Wo) continue;
+            a = fmaf(wc[(kt * 3 + kh) * 3 + kw], ET<T>::ld(db + (1 + ((long)to * Ho + hn / sh) * Wo + wn / sw) * C), a);
+          }
+        }
+      }
+    }
+    ET<T>::st(dx + i, a);
+  }
+}
+
+// dW[c][tap] partials: each block covers a slice of (b, output token) pairs.  256 / HD thread groups split the slice;
+// a thread owns one channel of the head being processed, so every LDS slot has one writer and the fold over heads and
+// groups runs in a fixed order (deterministic).
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void pool_conv_bwd_weight_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw, int heads,
+                                                                   const T* __restrict__ dpre, const T* __restrict__ x,
+                                                                   float* __restrict__ part) {
+  constexpr int NG = 256 / HD;
+  __shared__ float red[NG][27 * HD];
+  const int C = heads * HD;
+  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
+  const long pairs = (long)B * (n_out - 1);
+  const long per = (pairs + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = min(pairs, p0 + per);
+  const int grp = threadIdx.x / HD, ch = threadIdx.x % HD;
+  const bool worker = grp < NG;
+  float tot[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) tot[k] = 0.f;
+  if (worker) {
+    for (int hh = 0; hh < heads; ++hh) {
+      const int c = hh * HD + ch;
+      for (long p = p0 + grp; p < p1; p += NG) {
+        const int b = (int)(p / (n_out - 1));
+        const long r = p % (n_out - 1);
+        const int to = (int)(r / ((long)Ho * Wo)), ho = (int)((r / Wo) % Ho), wo = (int)(r % Wo);
+        const float d = ET<T>::ld(dpre + ((long)b * n_out + 1 + r) * C + c);
+        const T* xb = x + (long)b * n_in * C + c;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          const int t = to + kt - 1;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int hh2 = ho * sh + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int ww = wo * sw + kw - 1;
+              if (t >= 0 && t < Tn && hh2 >= 0 && hh2 < H && ww >= 0 && ww < W)
+                tot[(kt * 3 + kh) * 3 + kw] = fmaf(d, ET<T>::ld(xb + (1 + ((long)t * H + hh2) * W + ww) * C), tot[(kt * 3 + kh) * 3 + kw]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) red[grp][ch * 27 + k] = tot[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a += red[g][i];
+    part[(long)blockIdx.x * 27 * HD + i] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MaxPool3d (1,3,3)/(1,2,2)/(0,1,1) on the residual path; arg = winning tap (kh*3+kw), 255 for the cls row
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int C, const T* __restrict__ x,
+                                                          T* __restrict__ y, uint8_t* __restrict__ arg) {
+  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
+  const long total = (long)B * n_out * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long bo = i / C;
+    const long o = bo % n_out;
+    const int b = (int)(bo / n_out);
+    const T* xb = x + (long)b * n_in * C + c;
+    if (o == 0) { y[i] = xb[0]; arg[i] = 255; continue; }
+    const long r = o - 1;
+    const int t = (int)(r / ((long)Ho * Wo)), ho = (int)((r / Wo) % Ho), wo = (int)(r % Wo);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = ho * 2 + kh - 1;
+      if (hh < 0 || hh >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = wo * 2 + kw - 1;
+        if (ww < 0 || ww >= W) continue;
+        const float v = ET<T>::ld(xb + (1 + ((long)t * H + hh) * W + ww) * C);
+        if (v > best || v != v) { best = v; bi = kh * 3 + kw; }      // strictly greater (or NaN): the first maximum wins, as ATen
+      }
+    }
+    ET<T>::st(y + i, best);
+    arg[i] = (uint8_t)bi;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int C, const T* __restrict__ dy,
+                                                          const uint8_t* __restrict__ arg, T* __restrict__ dx) {
+  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
+  const long total = (long)B * n_in * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long bn = i / C;
+    const long n = bn % n_in;
+    const int b = (int)(bn / n_in);
+    const long ob = (long)b * n_out * C + c;
+    float a = 0.f;
+    if (n == 0) {
+      a = ET<T>::ld(dy + ob);
+    } else {
+      const long r = n - 1;
+      const int t = (int)(r / ((long)H * W)), h = (int)((r / W) % H), w = (int)(r % W);
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hn = h - kh + 1;
+        if (hn < 0 || (hn & 1) || hn / 2 >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int wn = w - kw + 1;
+          if (wn < 0 || (wn & 1) || wn / 2 >= Wo) continue;
+          const long o = ob + (1 + ((long)t * Ho + hn / 2) * Wo + wn / 2) * C;
+          if (arg[o] == kh * 3 + kw) a += ET<T>::ld(dy + o);
+        }
+      }
+    }
+    ET<T>::st(dx + i, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[b,0] = cls + pos_class;  out[b,1+n] = x[b,n] + spatial[n % HW] + temporal[n / HW]
+template <typename T>
+__global__ __launch_bounds__(256) void pos_encoding_kernel(int B, int Tn, int HW, int C, const T* __restrict__ x, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos_class, const float* __restrict__ spatial,
+                                                           const float* __restrict__ temporal, T* __restrict__ out) {
+  const long n1 = 1 + (long)Tn * HW, total = (long)B * n1 * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long bn = i / C;
+    const long n = bn % n1;
+    const long b = bn / n1;
+    float v;
+    if (n == 0) v = cls[c] + pos_class[c];
+    else {
+      const long r = n - 1;
+      v = ET<T>::ld(x + (b * (n1 - 1) + r) * C + c) + (spatial[(r % HW) * C + c] + temporal[(r / HW) * C + c]);
+    }
+    ET<T>::st(out + i, v);
+  }
+}
+
+// rows[(b,to,ho,wo)][c*kt*kh*kw ...] of the stem convolution; clip is [B, Tc, Cc, H, W] fp32 (the module's input layout);
+// row width Kp >= Cc*KT*KH*KW, zero padded
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3d_kernel(int B, int Tc, int Cc, int H, int W, int KT, int KH, int KW, int st, int sh, int sw,
+                                                       int pt, int ph, int pw, int To, int Ho, int Wo, int Kp, const float* __restrict__ clip,
+                                                       T* __restrict__ rows) {
+  const long total = (long)B * To * Ho * Wo * Kp;
+  const int K = Cc * KT * KH * KW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const long row = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int kw = k % KW, kh = (k / KW) % KH, kt = (k / (KW * KH)) % KT, c = k / (KW * KH * KT);
+      const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho), to = (int)((row / ((long)Wo * Ho)) % To);
+      const long b = row / ((long)Wo * Ho * To);
+      const int t = to * st + kt - pt, h = ho * sh + kh - ph, w = wo * sw + kw - pw;
+      if (t >= 0 && t < Tc && h >= 0 && h < H && w >= 0 && w < W) v = clip[(((b * Tc + t) * Cc + c) * H + h) * W + w];
+    }
+    ET<T>::st(rows + i, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cross attention.  q [B, Lq, H*HD], k / v [B, Lk, H*HD] (heads interleaved), out [B, Lq, H*HD], lse [B, H, Lq].
+// One thread per query row (forward, dq) or key row (dk/dv); the other side streams through LDS in 32-row tiles.
+constexpr int XA_THREADS = 128, XA_TILE = 32;
+
+template <typename T, int HD> __device__ inline void xa_load(const T* p, float (&v)[HD]) {
+#pragma unroll
+  for (int c = 0; c < HD / 8; ++c) {
+    float t8[8];
+    load8(p + c * 8, t8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[c * 8 + j] = t8[j];
+  }
+}
+template <typename T, int HD> __device__ inline void xa_store(T* p, const float (&v)[HD]) {
+#pragma unroll
+  for (int c = 0; c < HD / 8; ++c) {
+    float t8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t8[j] = v[c * 8 + j];
+    store8(p + c * 8, t8);
+  }
+}
+template <typename T, int HD>
+__device__ inline void xa_tile(float* lds, const T* base, long ld, int row0, int nrows) {      // [XA_TILE][HD] fp32
+  for (int id = threadIdx.x; id < XA_TILE * (HD / 8); id += XA_THREADS) {
+    const int r = id / (HD / 8), c = id % (HD / 8);
+    float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < nrows) load8(base + (long)(row0 + r) * ld + c * 8, t8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[r * HD + c * 8 + j] = t8[j];
+  }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(int Lq, int Lk, int heads, float scale, const T* __restrict__ q,
+                                                               const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
+                                                               float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) float Ks[XA_TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[XA_TILE * HD];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * HD;
+  const int i = blockIdx.x * XA_THREADS + threadIdx.x;
+  const bool active = i < Lq;
+  float qv[HD], acc[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) { qv[e] = 0.f; acc[e] = 0.f; }
+  if (active) {
+    xa_load<T, HD>(q + ((long)b * Lq + i) * C + h * HD, qv);
+#pragma unroll
+    for (int e = 0; e < HD; ++e) qv[e] *= scale;
+  }
+  float m = -INFINITY, l = 0.f;
+  const T* kb = k + (long)b * Lk * C + h * HD;
+  const T* vb = v + (long)b * Lk * C + h * HD;
+  for (int k0 = 0; k0 < Lk; k0 += XA_TILE) {
+    const int nk = min(XA_TILE, Lk - k0);
+    __syncthreads();
+    xa_tile<T, HD>(Ks, kb, C, k0, nk);
+    xa_tile<T, HD>(Vs, vb, C, k0, nk);
+    __syncthreads();
+    if (!active) continue;
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) s = fmaf(qv[e], Ks[j * HD + e], s);
+      if (s > m) {                                       // rescale on a new maximum (online softmax)
+        const float corr = __expf(m - s);
+        l *= corr;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) acc[e] *= corr;
+        m = s;
+      }
+      const float p = __expf(s - m);
+      l += p;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) acc[e] = fmaf(p, Vs[j * HD + e], acc[e]);
+    }
+  }
+  if (active) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) acc[e] *= inv;
+    xa_store<T, HD>(out + ((long)b * Lq + i) * C + h * HD, acc);
+    lse[((long)b * heads + h) * Lq + i] = m + __logf(l);
+  }
+}
+
+// dq (thread per query) and delta = rowsum(do * o)
+template <typename T, int HD>
+__global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(int Lq, int Lk, int heads, float scale, const T* __restrict__ q,
+                                                                  const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ o,
+                                                                  const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                  float* __restrict__ delta, T* __restrict__ dq) {
+  __shared__ __attribute__((aligned(16))) float Ks[XA_TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[XA_TILE * HD];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * HD;
+  const int i = blockIdx.x * XA_THREADS + threadIdx.x;
+  const bool active = i < Lq;
+  float qv[HD], dov[HD], acc[HD];
+  float dl = 0.f, my_lse = 0.f;
+#pragma unroll
+  for (int e = 0; e < HD; ++e) { qv[e] = 0.f; dov[e] = 0.f; acc[e] = 0.f; }
+  if (active) {
+    const long off = ((long)b * Lq + i) * C + h * HD;
+    xa_load<T, HD>(q + off, qv);
+    xa_load<T, HD>(dout + off, dov);
+    float ov[HD];
+    xa_load<T, HD>(o + off, ov);
+#pragma unroll
+    for (int e = 0; e < HD; ++e) { dl = fmaf(dov[e], ov[e], dl); qv[e] *= scale; }
+    my_lse = lse[((long)b * heads + h) * Lq + i];
+    delta[((long)b * heads + h) * Lq + i] = dl;
+  }
+  const T* kb = k + (long)b * Lk * C + h * HD;
+  const T* vb = v + (long)b * Lk * C + h * HD;
+  for (int k0 = 0; k0 < Lk; k0 += XA_TILE) {
+    const int nk = min(XA_TILE, Lk - k0);
+    __syncthreads();
+    xa_tile<T, HD>(Ks, kb, C, k0, nk);
+    xa_tile<T, HD>(Vs, vb, C, k0, nk);
+    __syncthreads();
+    if (!active) continue;
+    for (int j = 0; j < nk; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) { s = fmaf(qv[e], Ks[j * HD + e], s); dp = fmaf(dov[e], Vs[j * HD + e], dp); }
+      const float ds = __expf(s - my_lse) * (dp - dl);
+#pragma unroll
+      for (int e = 0; e < HD; ++e) acc[e] = fmaf(ds, Ks[j * HD + e], acc[e]);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < HD; ++e) acc[e] *= scale;
+    xa_store<T, HD>(dq + ((long)b * Lq + i) * C + h * HD, acc);
+  }
+}
+
+// dk, dv (thread per key); queries, dout stream through LDS with their lse / delta
+template <typename T, int HD>
+__global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(int Lq, int Lk, int heads, float scale, const T* __restrict__ q,
+                                                                   const T* __restrict__ k, const T* __restrict__ v,
+                                                                   const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv) {
+  __shared__ __attribute__((aligned(16))) float Qs[XA_TILE * HD];
+  __shared__ __attribute__((aligned(16))) float Ds[XA_TILE * HD];
+  __shared__ float Ls[XA_TILE], Dl[XA_TILE];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * HD;
+  const int j = blockIdx.x * XA_THREADS + threadIdx.x;
+  const bool active = j < Lk;
+  float kv[HD], vv[HD], dkv[HD], dvv[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) { kv[e] = 0.f; vv[e] = 0.f; dkv[e] = 0.f; dvv[e] = 0.f; }
+  if (active) {
+    const long off = ((long)b * Lk + j) * C + h * HD;
+    xa_load<T, HD>(k + off, kv);
+    xa_load<T, HD>(v + off, vv);
+  }
+  const T* qb = q + (long)b * Lq * C + h * HD;
+  const T* db = dout + (long)b * Lq * C + h * HD;
+  const float* lb = lse + ((long)b * heads + h) * Lq;
+  const float* dlb = delta + ((long)b * heads + h) * Lq;
+  for (int q0 = 0; q0 < Lq; q0 += XA_TILE) {
+    const int nq = min(XA_TILE, Lq - q0);
+    __syncthreads();
+    xa_tile<T, HD>(Qs, qb, C, q0, nq);
+    xa_tile<T, HD>(Ds, db, C, q0, nq);
+    if (threadIdx.x < XA_TILE) {
+      Ls[threadIdx.x] = threadIdx.x < nq ? lb[q0 + threadIdx.x] : 0.f;
+      Dl[threadIdx.x] = threadIdx.x < nq ? dlb[q0 + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int i = 0; i < nq; ++i) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) { s = fmaf(Qs[i * HD + e], kv[e], s); dp = fmaf(Ds[i * HD + e], vv[e], dp); }
+      const float p = __expf(s * scale - Ls[i]);
+      const float ds = p * (dp - Dl[i]);
+#pragma unroll
+      for (int e = 0; e < HD; ++e) { dvv[e] = fmaf(p, Ds[i * HD + e], dvv[e]); dkv[e] = fmaf(ds, Qs[i * HD + e], dkv[e]); }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dkv[e] *= scale;
+    const long off = ((long)b * Lk + j) * C + h * HD;
+    xa_store<T, HD>(dk + off, dkv);
+    xa_store<T, HD>(dv + off, dvv);
+  }
+}
+
+static int grid_for(long work, int cap = 65536) { long g = (work + 255) / 256; return (int)(g > cap ? cap : (g < 1 ? 1 : g)); }
+
+}  // namespace vtx
+
+using namespace vtx;
+
+#define MV_DISPATCH(dtype_, HD_, F32_96, BF_96, F32_64, BF_64, who_)                                    \
+  do {                                                                                                  \
+    if ((HD_) == 96) { if ((dtype_) == VTX_F32) { F32_96; } else { BF_96; } }                          \
+    else if ((HD_) == 64) { if ((dtype_) == VTX_F32) { F32_64; } else { BF_64; } }                     \
+    else VTX_REQUIRE(false, VTX_EINVAL, "%s: head_dim %d unsupported (64 or 96)", who_, (HD_));         \
+  } while (0)
+
+static int pool_check(const vtx_pool_desc* d, const char* who) {
+  VTX_REQUIRE(d != nullptr, VTX_EINVAL, "%s: null descriptor", who);
+  VTX_REQUIRE(d->dtype == VTX_F32 || d->dtype == VTX_BF16, VTX_EINVAL, "%s: bad dtype", who);
+  VTX_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->heads > 0 && d->sh > 0 && d->sw > 0, VTX_EINVAL, "%s: bad shape", who);
+  return VTX_OK;
+}
+static inline int pooled(int n, int s) { return (n + 2 - 3) / s + 1; }        // kernel 3, padding 1
+
+extern "C" int vtx_pool_conv_ln_fwd(const vtx_pool_desc* d, const void* x, const float* w, const float* gamma, const float* beta,
+                                    float eps, void* pre, void* y, float* mean, float* rstd, void* stream) {
+  int rc = pool_check(d, "pool_conv_ln_fwd");
+  if (rc) return rc;
+  VTX_REQUIRE(x && w && gamma && beta && pre && y && mean && rstd, VTX_EINVAL, "pool_conv_ln_fwd: null pointer");
+  const int Ho = pooled(d->H, d->sh), Wo = pooled(d->W, d->sw);
+  const long units = (long)d->B * (1 + (long)d->T * Ho * Wo) * d->heads;
+  dim3 g(cdiv(units, 8)), blk(256);
+  hipStream_t st = as_stream(stream);
+#define L_(T_, HD_) hipLaunchKernelGGL((pool_conv_ln_fwd_kernel<T_, HD_>), g, blk, 0, st, d->B, d->T, d->H, d->W, Ho, Wo, d->sh, d->sw, d->heads, \
+                                       (const T_*)x, w, gamma, beta, eps, (T_*)pre, (T_*)y, mean, rstd)
+  MV_DISPATCH(d->dtype, d->hd, L_(float, 96), L_(bf16raw, 96), L_(float, 64), L_(bf16raw, 64), "pool_conv_ln_fwd");
+#undef L_
+  return check_launch("pool_conv_ln_fwd");
+}
+
+extern "C" size_t vtx_pool_conv_ln_bwd_workspace(const vtx_pool_desc* d) {
+  if (!d) return 0;
+  return ((size_t)1024 * 2 * d->hd + (size_t)512 * 27 * d->hd) * sizeof(float);
+}
+
+extern "C" int vtx_pool_conv_ln_bwd(const vtx_pool_desc* d, const void* dy, const void* x, const void* pre, const float* mean,
+                                    const float* rstd, const float* w, const float* gamma, void* dpre, void* dx, float* dw,
+                                    float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = pool_check(d, "pool_conv_ln_bwd");
+  if (rc) return rc;
+  VTX_REQUIRE(dy && x && pre && mean && rstd && w && gamma && dpre && dx && dw && dgamma && dbeta && workspace, VTX_EINVAL,
+              "pool_conv_ln_bwd: null pointer");
+  VTX_REQUIRE(ws_bytes >= vtx_pool_conv_ln_bwd_workspace(d), VTX_EWS, "pool_conv_ln_bwd: workspace too small");
+  const int Ho = pooled(d->H, d->sh), Wo = pooled(d->W, d->sw), C = d->heads * d->hd;
+  const long n_out = 1 + (long)d->T * Ho * Wo, units = (long)d->B * n_out * d->heads;
+  hipStream_t st = as_stream(stream);
+  float* part_ln = (float*)workspace;                        // [1024][2][hd]
+  float* part_w = part_ln + (size_t)1024 * 2 * d->hd;        // [512][27][hd]
+  const int nb_ln = (int)(cdiv(units, 8) > 1024 ? 1024 : cdiv(units, 8));
+  const long pairs = (long)d->B * (n_out - 1);
+  const int nb_w = (int)(pairs < 512 ? (pairs > 0 ? pairs : 1) : 512);
+  const long in_elems = (long)d->B * (1 + (long)d->T * d->H * d->W) * C;
+#define LN_(T_, HD_) hipLaunchKernelGGL((pool_ln_bwd_kernel<T_, HD_>), dim3(nb_ln), dim3(256), 0, st, units, d->heads, (const T_*)dy, (const T_*)pre, \
+                                        mean, rstd, gamma, (T_*)dpre, part_ln)
+  MV_DISPATCH(d->dtype, d->hd, LN_(float, 96), LN_(bf16raw, 96), LN_(float, 64), LN_(bf16raw, 64), "pool_conv_ln_bwd");
+#undef LN_
+  rc = check_launch("pool_ln_bwd");
+  if (rc) return rc;
+  rc = launch_reduce_partials(part_ln, nb_ln, 2L * d->hd, 2L * d->hd, dgamma, 0, 1.0f, st, dbeta, d->hd, 0);
+  if (rc) return rc;
+#define BD_(T_, HD_) hipLaunchKernelGGL((pool_conv_bwd_data_kernel<T_, HD_>), dim3(grid_for(in_elems)), dim3(256), 0, st, d->B, d->T, d->H, d->W, Ho, Wo, \
+                                        d->sh, d->sw, C, (const T_*)dpre, w, (T_*)dx)
+  MV_DISPATCH(d->dtype, d->hd, BD_(float, 96), BD_(bf16raw, 96), BD_(float, 64), BD_(bf16raw, 64), "pool_conv_ln_bwd");
+#undef BD_
+  rc = check_launch("pool_conv_bwd_data");
+  if (rc) return rc;
+#define BW_(T_, HD_) hipLaunchKernelGGL((pool_conv_bwd_weight_kernel<T_, HD_>), dim3(nb_w), dim3(256), 0, st, d->B, d->T, d->H, d->W, Ho, Wo, d->sh, \
+                                        d->sw, d->heads, (const T_*)dpre, (const T_*)x, part_w)
+  MV_DISPATCH(d->dtype, d->hd, BW_(float, 96), BW_(bf16raw, 96), BW_(float, 64), BW_(bf16raw, 64), "pool_conv_ln_bwd");
+#undef BW_
+  rc = check_launch("pool_conv_bwd_weight");
+  if (rc) return rc;
+  return launch_reduce_partials(part_w, nb_w, 27L * d->hd, 27L * d->hd, dw, 0, 1.0f, st);
+}
+
+extern "C" int vtx_maxpool_skip_fwd(int dtype, int B, int T, int H, int W, int C, const void* x, void* y, uint8_t* arg, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && x && y && arg, VTX_EINVAL, "maxpool_skip_fwd: bad arguments");
+  const int Ho = pooled(H, 2), Wo = pooled(W, 2);
+  const long total = (long)B * (1 + (long)T * Ho * Wo) * C;
+  if (dtype == VTX_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, H, W, Ho, Wo, C, (const float*)x, (float*)y, arg);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, H, W, Ho, Wo, C, (const bf16raw*)x, (bf16raw*)y, arg);
+  return check_launch("maxpool_skip_fwd");
+}
+
+extern "C" int vtx_maxpool_skip_bwd(int dtype, int B, int T, int H, int W, int C, const void* dy, const uint8_t* arg, void* dx, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && dy && dx && arg, VTX_EINVAL, "maxpool_skip_bwd: bad arguments");
+  const int Ho = pooled(H, 2), Wo = pooled(W, 2);
+  const long total = (long)B * (1 + (long)T * H * W) * C;
+  if (dtype == VTX_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, H, W, Ho, Wo, C, (const float*)dy, arg, (float*)dx);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, H, W, Ho, Wo, C, (const bf16raw*)dy, arg, (bf16raw*)dx);
+  return check_launch("maxpool_skip_bwd");
+}
+
+extern "C" int vtx_pos_encoding_fwd(int dtype, int B, int T, int HW, int C, const void* x, const float* cls, const float* pos_class,
+                                    const float* spatial, const float* temporal, void* out, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && HW > 0 && C > 0 && x && cls && pos_class && spatial && temporal && out, VTX_EINVAL, "pos_encoding_fwd: bad arguments");
+  const long total = (long)B * (1 + (long)T * HW) * C;
+  if (dtype == VTX_F32)
+    hipLaunchKernelGGL(pos_encoding_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, HW, C, (const float*)x, cls, pos_class, spatial, temporal, (float*)out);
+  else
+    hipLaunchKernelGGL(pos_encoding_kernel<bf16raw>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, HW, C, (const bf16raw*)x, cls, pos_class, spatial, temporal, (bf16raw*)out);
+  return check_launch("pos_encoding_fwd");
+}
+
+extern "C" int vtx_im2col3d(int dtype, int B, int T, int C, int H, int W, const int* k3, const int* s3, const int* p3, int Kp,
+                            const float* clip, void* rows, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && C > 0 && H > 0 && W > 0 && k3 && s3 && p3 && clip && rows, VTX_EINVAL, "im2col3d: bad arguments");
+  VTX_REQUIRE(Kp >= C * k3[0] * k3[1] * k3[2] && Kp % 8 == 0, VTX_EINVAL, "im2col3d: row width must cover C*kt*kh*kw and be a multiple of 8");
+  const int To = (T + 2 * p3[0] - k3[0]) / s3[0] + 1, Ho = (H + 2 * p3[1] - k3[1]) / s3[1] + 1, Wo = (W + 2 * p3[2] - k3[2]) / s3[2] + 1;
+  const long total = (long)B * To * Ho * Wo * Kp;
+  if (dtype == VTX_F32)
+    hipLaunchKernelGGL(im2col3d_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, C, H, W, k3[0], k3[1], k3[2], s3[0], s3[1], s3[2],
+                       p3[0], p3[1], p3[2], To, Ho, Wo, Kp, clip, (float*)rows);
+  else
+    hipLaunchKernelGGL(im2col3d_kernel<bf16raw>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, C, H, W, k3[0], k3[1], k3[2], s3[0], s3[1], s3[2],
+                       p3[0], p3[1], p3[2], To, Ho, Wo, Kp, clip, (bf16raw*)rows);
+  return check_launch("im2col3d");
+}
+
+static int xattn_check(const vtx_xattn_desc* d, const char* who) {
+  VTX_REQUIRE(d != nullptr, VTX_EINVAL, "%s: null descriptor", who);
+  VTX_REQUIRE(d->dtype == VTX_F32 || d->dtype == VTX_BF16, VTX_EINVAL, "%s: bad dtype", who);
+  VTX_REQUIRE(d->B > 0 && d->Lq > 0 && d->Lk > 0 && d->heads > 0, VTX_EINVAL, "%s: bad shape", who);
+  VTX_REQUIRE(d->q && d->k && d->v && d->out && d->lse, VTX_EINVAL, "%s: null pointer", who);
+  VTX_REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->v) && aligned16(d->out), VTX_EALIGN, "%s: 16-byte alignment required", who);
+  return VTX_OK;
+}
+
+extern "C" int vtx_xattn_fwd(const vtx_xattn_desc* d, void* stream) {
+  int rc = xattn_check(d, "xattn_fwd");
+  if (rc) return rc;
+  dim3 g(cdiv(d->Lq, XA_THREADS), d->heads, d->B), blk(XA_THREADS);
+  hipStream_t st = as_stream(stream);
+#define L_(T_, HD_) hipLaunchKernelGGL((xattn_fwd_kernel<T_, HD_>), g, blk, 0, st, d->Lq, d->Lk, d->heads, d->scale, (const T_*)d->q, (const T_*)d->k, \
+                                       (const T_*)d->v, (T_*)d->out, d->lse)
+  MV_DISPATCH(d->dtype, d->hd, L_(float, 96), L_(bf16raw, 96), L_(float, 64), L_(bf16raw, 64), "xattn_fwd");
+#undef L_
+  return check_launch("xattn_fwd");
+}
+
+extern "C" int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, void* dk, void* dv, void* stream) {
+  int rc = xattn_check(d, "xattn_bwd");
+  if (rc) return rc;
+  VTX_REQUIRE(dout && delta && dq && dk && dv, VTX_EINVAL, "xattn_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  dim3 gq(cdiv(d->Lq, XA_THREADS), d->heads, d->B), gk(cdiv(d->Lk, XA_THREADS), d->heads, d->B), blk(XA_THREADS);
+#define Q_(T_, HD_) hipLaunchKernelGGL((xattn_bwd_dq_kernel<T_, HD_>), gq, blk, 0, st, d->Lq, d->Lk, d->heads, d->scale, (const T_*)d->q, (const T_*)d->k, \
+                                       (const T_*)d->v, (const T_*)d->out, (const T_*)dout, d->lse, delta, (T_*)dq)
+  MV_DISPATCH(d->dtype, d->hd, Q_(float, 96), Q_(bf16raw, 96), Q_(float, 64), Q_(bf16raw, 64), "xattn_bwd");
+#undef Q_
+  rc = check_launch("xattn_bwd_dq");
+  if (rc) return rc;
+#define K_(T_, HD_) hipLaunchKernelGGL((xattn_bwd_dkv_kernel<T_, HD_>), gk, blk, 0, st, d->Lq, d->Lk, d->heads, d->scale, (const T_*)d->q, (const T_*)d->k, \
+                                       (const T_*)d->v, (const T_*)dout, d->lse, delta, (T_*)dk, (T_*)dv)
+  MV_DISPATCH(d->dtype, d->hd, K_(float, 96), K_(bf16raw, 96), K_(float, 64), K_(bf16raw, 64), "xattn_bwd");
+#undef K_
+  return check_launch("xattn_bwd_dkv");
+}

@@ -18,6 +18,7 @@ from vtx import ops
 from transformer import PatchEmbed, TransformerContainer, get_sine_cosine_pos_emb
 from weight_init import (trunc_normal_, init_from_vit_pretrain_, init_from_mae_pretrain_,
                          init_from_kinetics_pretrain_)
+from mvit import (PatchEmbeding, create_conv_patch_embed, create_multiscale_vision_transformers)  # noqa: F401
 
 
 def _embed(param_or_tensor, device):
@@ -287,11 +288,9 @@ class ViViT(_VideoTransformerBase):
 
 
 # ------------------------------------------------------------------------------------
-# MaskFeat head (reference video_transformer.py:803-922).  The MViT-B backbone is
-# built by the reference from pytorchvideo (not installed here, SURVEY.md section 8(f)
-# rank 1); it can be injected with ``backbone=``.  Everything the reference's own
-# code computes around it -- mask-token blend, decoder, HOG-target masked MSE --
-# runs on libvtx kernels.
+# MaskFeat (reference video_transformer.py:803-922): MViT-B backbone (mvit.py -- native replacement of
+# the pytorchvideo modules the reference imports) + mask-token blend, decoder and HOG-target masked MSE,
+# all on libvtx kernels.
 # ------------------------------------------------------------------------------------
 class _MaskBlendFn(torch.autograd.Function):
     @staticmethod
@@ -370,19 +369,17 @@ class MaskFeat(nn.Module):
         self.stride = conv_patch_embed_stride
         self.downsample_rate = 2 ** len(pool_q_stride_size)
         self.embed_dims = 2 ** len(embed_dim_mul) * patch_embed_dim
-        # conv patch embed of the MViT stem (overlapping, padded): part of the backbone row
-        # (SURVEY.md section 8(f) rank 1); parameters keep the reference's key names.
-        self.patch_embed = nn.Module()
-        self.patch_embed.patch_model = nn.Conv3d(input_channels, patch_embed_dim,
-                                                 kernel_size=conv_patch_embed_kernel,
-                                                 stride=conv_patch_embed_stride,
-                                                 padding=conv_patch_embed_padding, bias=True)
-        if backbone is None:
-            raise NotImplementedError(
-                'vtx: the MViT-B backbone comes from pytorchvideo in the reference '
-                '(video_transformer.py:15-17,844-852), which is not installed; pass backbone=<module mapping '
-                '[B, L, 96] tokens to [B, 1+L/16, 768] features> (SURVEY.md section 8(f) rank 1)')
-        self.mvit = backbone
+        self.patch_embed = create_conv_patch_embed(in_channels=input_channels, out_channels=patch_embed_dim,
+                                                   conv_kernel_size=conv_patch_embed_kernel,
+                                                   conv_stride=conv_patch_embed_stride,
+                                                   conv_padding=conv_patch_embed_padding, conv=nn.Conv3d)
+        if backbone is not None:                  # beyond the reference: any module mapping [B, L, 96] -> [B, 1+L/16, 768]
+            self.mvit = backbone
+        else:
+            self.mvit = create_multiscale_vision_transformers(
+                spatial_size=img_size, temporal_size=num_frames, embed_dim_mul=embed_dim_mul, atten_head_mul=atten_head_mul,
+                pool_q_stride_size=pool_q_stride_size, pool_kv_stride_adaptive=pool_kv_stride_adaptive,
+                pool_kvq_kernel=pool_kvq_kernel, head=head)
         self.decoder_pred = nn.Linear(self.embed_dims, feature_dim, bias=True)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, patch_embed_dim))
         w = self.patch_embed.patch_model.weight.data
@@ -412,7 +409,7 @@ class MaskFeat(nn.Module):
                                   (B, tq, hq, wq, Cc, g))
 
     def forward_features(self, x, mask=None):
-        x = self.patch_embed.patch_model(x.transpose(1, 2)).flatten(2).transpose(1, 2).contiguous()
+        x = self.patch_embed(x.transpose(1, 2))
         if mask is not None:
             x = self.blend_mask_tokens(x, mask)
         return self.mvit(x)

@@ -56,6 +56,16 @@ class MtTensor(C.Structure):
                 ('lr', C.c_float), ('wd', C.c_float)]
 
 
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('dtype', 'B', 'T', 'H', 'W', 'heads', 'hd', 'sh', 'sw')]
+
+
+class XAttnDesc(C.Structure):
+    _fields_ = [('dtype', C.c_int), ('B', C.c_int), ('Lq', C.c_int), ('Lk', C.c_int), ('heads', C.c_int), ('hd', C.c_int),
+                ('scale', C.c_float), ('q', C.c_void_p), ('k', C.c_void_p), ('v', C.c_void_p), ('out', C.c_void_p),
+                ('lse', C.c_void_p)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ('dtype', C.c_int), ('mode', C.c_int),
@@ -100,6 +110,7 @@ SIGNATURES = {
     'vtx_cls_qkv_reduce': (ci, [ci, ci, ci, ci, vp, cl, vp, cl, cl, vp]),
     'vtx_row_scale_copy': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, ci, ci, ci, ci, vp]),
     'vtx_reduce_rows': (ci, [ci, ci, ci, ci, vp, cl, cl, cl, cl, vp, cl, cf, ci, vp]),
+    'vtx_gelu_grad_mul': (ci, [ci, sz, vp, vp, vp, vp]),
     'vtx_cast_transpose': (ci, [ci, ci, ci, vp, vp, vp, vp]),
     'vtx_cast_from_f32': (ci, [ci, sz, vp, vp, vp]),
     'vtx_cast_to_f32': (ci, [ci, sz, vp, vp, vp]),
@@ -113,6 +124,15 @@ SIGNATURES = {
     'vtx_maskfeat_blend_bwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_fwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_bwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, cf, vp, cl, vp]),
+    'vtx_pool_conv_ln_fwd': (ci, [C.POINTER(PoolDesc), vp, vp, vp, vp, cf, vp, vp, vp, vp, vp]),
+    'vtx_pool_conv_ln_bwd_workspace': (sz, [C.POINTER(PoolDesc)]),
+    'vtx_pool_conv_ln_bwd': (ci, [C.POINTER(PoolDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'vtx_maxpool_skip_fwd': (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_maxpool_skip_bwd': (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_pos_encoding_fwd': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+    'vtx_im2col3d': (ci, [ci, ci, ci, ci, ci, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), ci, vp, vp, vp]),
+    'vtx_xattn_fwd': (ci, [C.POINTER(XAttnDesc), vp]),
+    'vtx_xattn_bwd': (ci, [C.POINTER(XAttnDesc), vp, vp, vp, vp, vp, vp]),
     'vtx_mixup_batch': (ci, [vp, ci, cl, cf, cf, vp]),
     'vtx_cutmix_batch': (ci, [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     'vtx_mixup_target': (ci, [vp, ci, ci, cf, cf, cf, cf, vp, vp]),

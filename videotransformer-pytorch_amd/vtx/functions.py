@@ -644,3 +644,259 @@ class SoftmaxXentFn(torch.autograd.Function):
         ops.call('vtx_softmax_xent_bwd', ops.ptr(logits), ops.ptr(target) if ctx.soft else None,
                  None if ctx.soft else ops.ptr(target), ops.ptr(lse), B, Cn, 1.0 / B, ops.ptr(gloss), ops.ptr(d), ops.stream())
         return d, None
+
+
+# ---------------------------------------------------------------------------------
+# MViT backbone operators (csrc/mvit.hip; reference video_transformer.py:621-800 via pytorchvideo)
+# ---------------------------------------------------------------------------------
+def _pool_desc(x, thw, heads, stride):
+    from ._lib import PoolDesc
+    B, N1, Cn = x.shape
+    T, H, W = thw
+    if N1 != 1 + T * H * W:
+        raise ValueError(f'{N1 - 1} tokens do not form a {T}x{H}x{W} grid')
+    if stride[0] != 1:
+        raise NotImplementedError('vtx: pooling with a temporal stride is not implemented (MViT-B pools space only)')
+    d = PoolDesc()
+    d.dtype = ops.dt(x); d.B, d.T, d.H, d.W = B, T, H, W
+    d.heads, d.hd, d.sh, d.sw = heads, Cn // heads, int(stride[1]), int(stride[2])
+    return d
+
+
+def pooled_thw(thw, stride):
+    return [thw[0], (thw[1] - 1) // stride[1] + 1, (thw[2] - 1) // stride[2] + 1]
+
+
+class PoolConvLNFn(torch.autograd.Function):
+    """Pooling of q / k / v in MultiScaleAttention: depthwise Conv3d(3x3x3, stride, padding 1) per head on the
+    token grid + LayerNorm(head_dim); cls token bypasses the conv.  x [B, 1+T*H*W, heads*hd]."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, ln_w, ln_b, thw, heads, stride, eps):
+        import ctypes as C
+        x = _chk(x)
+        d = _pool_desc(x, thw, heads, stride)
+        if tuple(conv_w.shape[2:]) != (3, 3, 3):
+            raise NotImplementedError('vtx: pooling kernels other than 3x3x3 are not implemented')
+        T, Ho, Wo = pooled_thw(thw, stride)
+        B, _, Cn = x.shape
+        n_out = 1 + T * Ho * Wo
+        pre = _empty((B, n_out, Cn), x)
+        y = _empty((B, n_out, Cn), x)
+        mean = _empty((B * n_out * heads,), x, torch.float32)
+        rstd = _empty((B * n_out * heads,), x, torch.float32)
+        w = conv_w.detach().reshape(d.hd, 27).contiguous()
+        ops.call('vtx_pool_conv_ln_fwd', C.byref(d), ops.ptr(x), ops.ptr(w), ops.ptr(ln_w), ops.ptr(ln_b), float(eps),
+                 ops.ptr(pre), ops.ptr(y), ops.ptr(mean), ops.ptr(rstd), ops.stream())
+        ctx.save_for_backward(x, pre, mean, rstd, w, ln_w)
+        ctx.cfg = (tuple(thw), heads, tuple(stride), tuple(conv_w.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        x, pre, mean, rstd, w, ln_w = ctx.saved_tensors
+        thw, heads, stride, w_shape = ctx.cfg
+        dy = _chk(dy)
+        d = _pool_desc(x, thw, heads, stride)
+        dpre = torch.empty_like(pre)
+        dx = torch.empty_like(x)
+        dw = torch.empty(d.hd, 27, dtype=torch.float32, device=x.device)
+        dg = torch.empty(d.hd, dtype=torch.float32, device=x.device)
+        db = torch.empty(d.hd, dtype=torch.float32, device=x.device)
+        ws_bytes = _lib_load().vtx_pool_conv_ln_bwd_workspace(C.byref(d))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        ops.call('vtx_pool_conv_ln_bwd', C.byref(d), ops.ptr(dy), ops.ptr(x), ops.ptr(pre), ops.ptr(mean), ops.ptr(rstd),
+                 ops.ptr(w), ops.ptr(ln_w), ops.ptr(dpre), ops.ptr(dx), ops.ptr(dw), ops.ptr(dg), ops.ptr(db), ops.ptr(ws),
+                 ws_bytes, ops.stream())
+        return dx, dw.reshape(w_shape), dg, db, None, None, None, None
+
+
+def _lib_load():
+    from . import _lib
+    return _lib.load()
+
+
+class MaxPoolSkipFn(torch.autograd.Function):
+    """Residual-path MaxPool3d(kernel (1,3,3), stride (1,2,2), padding (0,1,1)) of MultiScaleBlock; cls row kept."""
+
+    @staticmethod
+    def forward(ctx, x, thw):
+        x = _chk(x)
+        B, N1, Cn = x.shape
+        T, H, W = thw
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = _empty((B, 1 + T * Ho * Wo, Cn), x)
+        arg = torch.empty(B, 1 + T * Ho * Wo, Cn, dtype=torch.uint8, device=x.device)
+        ops.call('vtx_maxpool_skip_fwd', ops.dt(x), B, T, H, W, Cn, ops.ptr(x), ops.ptr(y), ops.ptr(arg), ops.stream())
+        ctx.save_for_backward(arg)
+        ctx.cfg = (B, T, H, W, Cn, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, T, H, W, Cn, dtype = ctx.cfg
+        dy = _chk(dy)
+        dx = torch.empty(B, 1 + T * H * W, Cn, dtype=dtype, device=dy.device)
+        ops.call('vtx_maxpool_skip_bwd', ops.dt(dy), B, T, H, W, Cn, ops.ptr(dy), ops.ptr(arg), ops.ptr(dx), ops.stream())
+        return dx, None
+
+
+class XAttnFn(torch.autograd.Function):
+    """softmax(q k^T hd^-0.5) v with separately pooled q [B,Lq,C] and k, v [B,Lk,C] (heads interleaved in C)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        from ._lib import XAttnDesc
+        q, k, v = _chk(q), _chk(k), _chk(v)
+        B, Lq, Cn = q.shape
+        out = torch.empty_like(q)
+        lse = torch.empty(B * heads * Lq, dtype=torch.float32, device=q.device)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.heads = heads
+        XAttnFn._call('vtx_xattn_fwd', q, k, v, out, lse, heads)
+        return out
+
+    @staticmethod
+    def _desc(q, k, v, out, lse, heads):
+        from ._lib import XAttnDesc
+        d = XAttnDesc()
+        B, Lq, Cn = q.shape
+        d.dtype = ops.dt(q); d.B, d.Lq, d.Lk, d.heads, d.hd = B, Lq, k.shape[1], heads, Cn // heads
+        d.scale = float((Cn // heads) ** -0.5)
+        d.q, d.k, d.v, d.out, d.lse = ops.ptr(q), ops.ptr(k), ops.ptr(v), ops.ptr(out), ops.ptr(lse)
+        return d
+
+    @staticmethod
+    def _call(name, q, k, v, out, lse, heads, *extra):
+        import ctypes as C
+        d = XAttnFn._desc(q, k, v, out, lse, heads)
+        ops.call(name, C.byref(d), *extra, ops.stream())
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dout = _chk(dout)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        XAttnFn._call('vtx_xattn_bwd', q, k, v, out, lse, ctx.heads, ops.ptr(dout), ops.ptr(delta), ops.ptr(dq), ops.ptr(dk),
+                      ops.ptr(dv))
+        return dq, dk, dv, None
+
+
+class PosEncodingFn(torch.autograd.Function):
+    """SpatioTemporalClsPositionalEncoding (separable): cls token prepended, pos_embed_spatial repeated over T +
+    pos_embed_temporal repeat-interleaved over H*W + pos_embed_class."""
+
+    @staticmethod
+    def forward(ctx, x, cls, pos_class, spatial, temporal):
+        x = _chk(x)
+        B, N, Cn = x.shape
+        T, HW = temporal.shape[-2], spatial.shape[-2]
+        if N != T * HW:
+            raise ValueError(f'{N} tokens but the position tables cover {T} x {HW}')
+        out = _empty((B, 1 + N, Cn), x)
+        ops.call('vtx_pos_encoding_fwd', ops.dt(x), B, T, HW, Cn, ops.ptr(x), ops.ptr(cls.detach().reshape(-1).contiguous()),
+                 ops.ptr(pos_class.detach().reshape(-1).contiguous()), ops.ptr(spatial.detach().reshape(HW, Cn).contiguous()),
+                 ops.ptr(temporal.detach().reshape(T, Cn).contiguous()), ops.ptr(out), ops.stream())
+        ctx.cfg = (B, T, HW, Cn, cls.shape, pos_class.shape, spatial.shape, temporal.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, HW, Cn, cls_s, pc_s, sp_s, tp_s = ctx.cfg
+        dy = _chk(dy)
+        N1 = 1 + T * HW
+        dx = dy[:, 1:].contiguous()
+        d_cls = ops.reduce_rows(dy, 1, B, Cn, Cn, 0, N1, 0)                                  # sum_b dy[b, 0]
+        d_sp = torch.empty(HW, Cn, dtype=torch.float32, device=dy.device)
+        d_tp = torch.empty(T, Cn, dtype=torch.float32, device=dy.device)
+        for b in range(B):
+            ops.reduce_rows(dy, HW, T, Cn, Cn, b * N1 + 1, HW, 1, out=d_sp, accumulate=b > 0)     # sum_t dy[b, 1 + t*HW + hw]
+            ops.reduce_rows(dy, T, HW, Cn, Cn, b * N1 + 1, 1, HW, out=d_tp, accumulate=b > 0)     # sum_hw
+        return dx, d_cls.reshape(cls_s), d_cls.clone().reshape(pc_s), d_sp.reshape(sp_s), d_tp.reshape(tp_s)
+
+
+class ConvStemFn(torch.autograd.Function):
+    """Overlapping, padded Conv3d patch embedding of the MViT stem (create_conv_patch_embed, reference
+    video_transformer.py:585-618, 834-843): im2col gather + GEMM, tokens [B, T'*H'*W', D] out.  clip [B,T,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, clip, conv_w, conv_b, stride, padding, dtype):
+        import ctypes as C
+        ops.need_cuda(clip, conv_w)
+        clip = clip.float().contiguous()
+        B, T, Cc, H, W = clip.shape
+        D, _, KT, KH, KW = conv_w.shape
+        K = Cc * KT * KH * KW
+        Kp = (K + 63) // 64 * 64                       # whole 64-deep K tiles: the LDS-DMA GEMM kernels apply
+        To = (T + 2 * padding[0] - KT) // stride[0] + 1
+        Ho = (H + 2 * padding[1] - KH) // stride[1] + 1
+        Wo = (W + 2 * padding[2] - KW) // stride[2] + 1
+        M = B * To * Ho * Wo
+        rows = torch.empty(M, Kp, dtype=dtype, device=clip.device)
+        i3 = lambda t: (C.c_int * 3)(*[int(v) for v in t])   # noqa: E731
+        from . import ops as _o
+        ops.call('vtx_im2col3d', _o._DT[dtype], B, T, Cc, H, W, i3((KT, KH, KW)), i3(stride), i3(padding), Kp, ops.ptr(clip),
+                 ops.ptr(rows), ops.stream())
+        w_pad = torch.zeros(D, Kp, dtype=torch.float32, device=conv_w.device)
+        w_pad[:, :K].copy_(conv_w.detach().reshape(D, K))
+        wc, _ = ops.cast_transpose(w_pad, dtype, want_c=True, want_t=False)
+        y = torch.empty(M, D, dtype=dtype, device=clip.device)
+        ops.gemm_nt(rows, wc, y, M, D, Kp, bias=conv_b)
+        ctx.save_for_backward(rows)
+        ctx.cfg = (M, D, K, Kp, tuple(conv_w.shape))
+        return y.reshape(B, To * Ho * Wo, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        M, D, K, Kp, w_shape = ctx.cfg
+        dy = _chk(dy).reshape(M, D)
+        d_w, d_b = ops.gemm_tn(dy, rows, M, D, Kp, want_colsum=True)
+        return None, d_w[:, :K].reshape(w_shape), d_b, None, None, None
+
+
+class LinearActResFn(torch.autograd.Function):
+    """y = act(x W^T + b) (+ res): a Linear with the GELU and / or the residual add of its consumer fused into the
+    GEMM epilogue (MViT Mlp.fc1 + GELU; attn.proj / Mlp.fc2 + skip connection).  Output width a multiple of 8."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gelu, res):
+        x = _chk(x)
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        wc, wT = weights(w, x.dtype, any(ctx.needs_input_grad))
+        y = _empty((M, N), x)
+        h = _empty((M, N), x) if gelu else None
+        if res is not None:
+            res = _chk(res)
+        ops.gemm_nt(x, wc, y, M, N, K, bias=b, act=1 if gelu else 0, C2=h, R=res)
+        ctx.save_for_backward(x, *( [h] if gelu else []), *([wT] if wT is not None else []))
+        ctx.cfg = (gelu, b is not None, res is not None, N)
+        return y.reshape(tuple(x.shape[:-1]) + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        gelu, has_bias, has_res, N = ctx.cfg
+        saved = ctx.saved_tensors
+        x = saved[0]
+        h = saved[1] if gelu else None
+        wT = saved[-1]
+        K = x.shape[-1]
+        M = x.numel() // K
+        dy = _chk(dy).reshape(M, N)
+        if gelu:                                        # d(pre-activation) = dy * gelu'(h)
+            dz = _empty((M, N), x)
+            ops.gelu_grad_mul(dy, h, dz)
+        else:
+            dz = dy
+        if has_bias:
+            d_w, d_b = ops.gemm_tn(dz, x, M, N, K, want_colsum=True)
+        else:
+            d_w, d_b = ops.gemm_tn(dz, x, M, N, K), None
+        dx = torch.empty_like(x)
+        ops.gemm_nt(dz, wT, dx, M, K, N)
+        return dx, d_w, d_b, None, (dy.reshape(x.shape[:-1] + (N,)) if has_res else None)

@@ -491,3 +491,9 @@ def topk_correct(scores, labels, k, counter):
     labels = labels.long().contiguous()
     B, Cn = scores.shape
     call('vtx_topk_correct', ptr(scores), ptr(labels), B, Cn, int(k), ptr(counter), stream())
+
+
+def gelu_grad_mul(dy, h, out):
+    """out = dy * gelu'(h) elementwise (same shapes / dtype, numel % 8 == 0)."""
+    need_cuda(dy, h, out)
+    call('vtx_gelu_grad_mul', dt(dy), dy.numel(), ptr(dy), ptr(h), ptr(out), stream())
