@@ -281,7 +281,8 @@ int vtx_pos_encoding_fwd(int dtype, int B, int T, int HW, int C, const void* x, 
 int vtx_im2col3d(int dtype, int B, int T, int C, int H, int W, const int* k3, const int* s3, const int* p3, int Kp,
                  const float* clip, void* rows, void* stream);
 /* softmax(q k^T * scale) v with separate q [B,Lq,heads*hd] and k, v [B,Lk,heads*hd]; lse [B,heads,Lq] fp32.
- * bwd: delta [B,heads,Lq] fp32 scratch. */
+ * bwd: delta [B,heads,Lq] fp32 scratch; workspace (vtx_xattn_bwd_workspace bytes): fp32 partial dk / dv of the query
+ * splits that keep the chip busy when the keys are few (393 pooled keys against 25 089 queries in MViT block 0). */
 typedef struct {
   int dtype, B, Lq, Lk, heads, hd;
   float scale;
@@ -289,7 +290,9 @@ typedef struct {
   void* out; float* lse;
 } vtx_xattn_desc;
 int vtx_xattn_fwd(const vtx_xattn_desc* d, void* stream);
-int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, void* dk, void* dv, void* stream);
+size_t vtx_xattn_bwd_workspace(const vtx_xattn_desc* d);
+int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, void* dk, void* dv, void* workspace,
+                  size_t ws_bytes, void* stream);
 
 /* ------------------------------------------- clip-batch mixing, classification loss, accuracy
  * Mixup / CutMix of the clip batch in place (mixup.py:102-126; the numpy draws stay on the host): x is

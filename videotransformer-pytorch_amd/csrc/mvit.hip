@@ -472,12 +472,18 @@ template <typename T, int HD>
 __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(int Lq, int Lk, int heads, float scale, const T* __restrict__ q,
                                                                    const T* __restrict__ k, const T* __restrict__ v,
                                                                    const T* __restrict__ dout, const float* __restrict__ lse,
-                                                                   const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv) {
+                                                                   const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
+                                                                   int kblocks, int q_per_split, float* __restrict__ part_k,
+                                                                   float* __restrict__ part_v, long part_stride) {
+  // A key row is one thread; with few keys (393 after pooling) and many queries (25 089) the query range is cut into
+  // splits (blockIdx.x / kblocks) whose fp32 partial dk / dv are summed by xattn_reduce_kernel in split order.
   __shared__ __attribute__((aligned(16))) float Qs[XA_TILE * HD];
   __shared__ __attribute__((aligned(16))) float Ds[XA_TILE * HD];
   __shared__ float Ls[XA_TILE], Dl[XA_TILE];
   const int b = blockIdx.z, h = blockIdx.y, C = heads * HD;
-  const int j = blockIdx.x * XA_THREADS + threadIdx.x;
+  const int split = blockIdx.x / kblocks;
+  const int j = (blockIdx.x - split * kblocks) * XA_THREADS + threadIdx.x;
+  const int q_begin = split * q_per_split, q_end = min(Lq, q_begin + q_per_split);
   const bool active = j < Lk;
   float kv[HD], vv[HD], dkv[HD], dvv[HD];
 #pragma unroll
@@ -491,8 +497,8 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(int Lq, int L
   const T* db = dout + (long)b * Lq * C + h * HD;
   const float* lb = lse + ((long)b * heads + h) * Lq;
   const float* dlb = delta + ((long)b * heads + h) * Lq;
-  for (int q0 = 0; q0 < Lq; q0 += XA_TILE) {
-    const int nq = min(XA_TILE, Lq - q0);
+  for (int q0 = q_begin; q0 < q_end; q0 += XA_TILE) {
+    const int nq = min(XA_TILE, q_end - q0);
     __syncthreads();
     xa_tile<T, HD>(Qs, qb, C, q0, nq);
     xa_tile<T, HD>(Ds, db, C, q0, nq);
@@ -516,8 +522,28 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(int Lq, int L
 #pragma unroll
     for (int e = 0; e < HD; ++e) dkv[e] *= scale;
     const long off = ((long)b * Lk + j) * C + h * HD;
-    xa_store<T, HD>(dk + off, dkv);
-    xa_store<T, HD>(dv + off, dvv);
+    if (part_k == nullptr) {
+      xa_store<T, HD>(dk + off, dkv);
+      xa_store<T, HD>(dv + off, dvv);
+    } else {
+      xa_store<float, HD>(part_k + split * part_stride + off, dkv);
+      xa_store<float, HD>(part_v + split * part_stride + off, dvv);
+    }
+  }
+}
+
+// out[i] = sum over splits (in order) of part[s][i], converted to T
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_reduce_kernel(const float* __restrict__ part, int nsplit, long stride, long n8, T* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sp = 0; sp < nsplit; ++sp) {
+      float t[8];
+      load8(part + sp * stride + i * 8, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += t[e];
+    }
+    store8(out + i * 8, a);
   }
 }
 
@@ -672,12 +698,35 @@ extern "C" int vtx_xattn_fwd(const vtx_xattn_desc* d, void* stream) {
   return check_launch("xattn_fwd");
 }
 
-extern "C" int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, void* dk, void* dv, void* stream) {
+static int xattn_splits(const vtx_xattn_desc* d) {
+  const int kblocks = cdiv(d->Lk, XA_THREADS);
+  const long blocks = (long)kblocks * d->heads * d->B;
+  int s = (int)(1024 / (blocks > 0 ? blocks : 1));             // aim at ~4 workgroups per CU
+  const int max_s = cdiv(d->Lq, 4 * XA_TILE);                  // at least 4 query tiles per split
+  if (s > max_s) s = max_s;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t vtx_xattn_bwd_workspace(const vtx_xattn_desc* d) {
+  if (!d) return 0;
+  const int s = xattn_splits(d);
+  return s > 1 ? (size_t)2 * s * d->B * d->Lk * d->heads * d->hd * sizeof(float) : 16;
+}
+
+extern "C" int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, void* dk, void* dv, void* workspace,
+                             size_t ws_bytes, void* stream) {
   int rc = xattn_check(d, "xattn_bwd");
   if (rc) return rc;
-  VTX_REQUIRE(dout && delta && dq && dk && dv, VTX_EINVAL, "xattn_bwd: null pointer");
+  VTX_REQUIRE(dout && delta && dq && dk && dv && workspace, VTX_EINVAL, "xattn_bwd: null pointer");
+  VTX_REQUIRE(ws_bytes >= vtx_xattn_bwd_workspace(d), VTX_EWS, "xattn_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  dim3 gq(cdiv(d->Lq, XA_THREADS), d->heads, d->B), gk(cdiv(d->Lk, XA_THREADS), d->heads, d->B), blk(XA_THREADS);
+  const int kblocks = cdiv(d->Lk, XA_THREADS), nsplit = xattn_splits(d);
+  const int q_per = cdiv(cdiv(d->Lq, nsplit), XA_TILE) * XA_TILE;
+  const long part_stride = (long)d->B * d->Lk * d->heads * d->hd;
+  float* part_k = nsplit > 1 ? (float*)workspace : nullptr;
+  float* part_v = nsplit > 1 ? part_k + (size_t)nsplit * part_stride : nullptr;
+  dim3 gq(cdiv(d->Lq, XA_THREADS), d->heads, d->B), gk(kblocks * nsplit, d->heads, d->B), blk(XA_THREADS);
 #define Q_(T_, HD_) hipLaunchKernelGGL((xattn_bwd_dq_kernel<T_, HD_>), gq, blk, 0, st, d->Lq, d->Lk, d->heads, d->scale, (const T_*)d->q, (const T_*)d->k, \
                                        (const T_*)d->v, (const T_*)d->out, (const T_*)dout, d->lse, delta, (T_*)dq)
   MV_DISPATCH(d->dtype, d->hd, Q_(float, 96), Q_(bf16raw, 96), Q_(float, 64), Q_(bf16raw, 64), "xattn_bwd");
@@ -685,8 +734,18 @@ extern "C" int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* d
   rc = check_launch("xattn_bwd_dq");
   if (rc) return rc;
 #define K_(T_, HD_) hipLaunchKernelGGL((xattn_bwd_dkv_kernel<T_, HD_>), gk, blk, 0, st, d->Lq, d->Lk, d->heads, d->scale, (const T_*)d->q, (const T_*)d->k, \
-                                       (const T_*)d->v, (const T_*)dout, d->lse, delta, (T_*)dk, (T_*)dv)
+                                       (const T_*)d->v, (const T_*)dout, d->lse, delta, (T_*)dk, (T_*)dv, kblocks, q_per, part_k, part_v, part_stride)
   MV_DISPATCH(d->dtype, d->hd, K_(float, 96), K_(bf16raw, 96), K_(float, 64), K_(bf16raw, 64), "xattn_bwd");
 #undef K_
-  return check_launch("xattn_bwd_dkv");
+  rc = check_launch("xattn_bwd_dkv");
+  if (rc || nsplit == 1) return rc;
+  const long n8 = part_stride / 8;
+  if (d->dtype == VTX_F32) {
+    hipLaunchKernelGGL(xattn_reduce_kernel<float>, dim3(grid_for(n8)), dim3(256), 0, st, part_k, nsplit, part_stride, n8, (float*)dk);
+    hipLaunchKernelGGL(xattn_reduce_kernel<float>, dim3(grid_for(n8)), dim3(256), 0, st, part_v, nsplit, part_stride, n8, (float*)dv);
+  } else {
+    hipLaunchKernelGGL(xattn_reduce_kernel<bf16raw>, dim3(grid_for(n8)), dim3(256), 0, st, part_k, nsplit, part_stride, n8, (bf16raw*)dk);
+    hipLaunchKernelGGL(xattn_reduce_kernel<bf16raw>, dim3(grid_for(n8)), dim3(256), 0, st, part_v, nsplit, part_stride, n8, (bf16raw*)dv);
+  }
+  return check_launch("xattn_reduce");
 }

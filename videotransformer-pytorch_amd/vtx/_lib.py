@@ -132,7 +132,8 @@ SIGNATURES = {
     'vtx_pos_encoding_fwd': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     'vtx_im2col3d': (ci, [ci, ci, ci, ci, ci, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), ci, vp, vp, vp]),
     'vtx_xattn_fwd': (ci, [C.POINTER(XAttnDesc), vp]),
-    'vtx_xattn_bwd': (ci, [C.POINTER(XAttnDesc), vp, vp, vp, vp, vp, vp]),
+    'vtx_xattn_bwd_workspace': (sz, [C.POINTER(XAttnDesc)]),
+    'vtx_xattn_bwd': (ci, [C.POINTER(XAttnDesc), vp, vp, vp, vp, vp, vp, sz, vp]),
     'vtx_mixup_batch': (ci, [vp, ci, cl, cf, cf, vp]),
     'vtx_cutmix_batch': (ci, [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     'vtx_mixup_target': (ci, [vp, ci, ci, cf, cf, cf, cf, vp, vp]),

@@ -780,8 +780,11 @@ class XAttnFn(torch.autograd.Function):
         dout = _chk(dout)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
+        import ctypes as C
+        ws_bytes = _lib_load().vtx_xattn_bwd_workspace(C.byref(XAttnFn._desc(q, k, v, out, lse, ctx.heads)))
+        ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device=q.device)
         XAttnFn._call('vtx_xattn_bwd', q, k, v, out, lse, ctx.heads, ops.ptr(dout), ops.ptr(delta), ops.ptr(dq), ops.ptr(dk),
-                      ops.ptr(dv))
+                      ops.ptr(dv), ops.ptr(ws), ws_bytes)
         return dq, dk, dv, None
 
 
