@@ -58,7 +58,9 @@ const char* vtx_last_error_string(void);
 /* Tuning / diagnostic switches (process-wide; initial values from the VTX_* environment variables,
  * read once): "gemm_nt" = auto|pp256|dma2|ring128x3|ring128x4k32|ring256x3|ring256x3k32|ring256x4k32,
  * "gemm_tn" = auto|pp256|ring|dma2, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "pp_grid", "pp_cg",
- * "pp_epi" = integers, "pp_skew" = float.  Returns VTX_EINVAL for an unknown name or value. */
+ * "pp_epi" = integers ("pp_epi": 1 = per-pass epilogue of the persistent GEMM; 2 / 3 = timing diagnostics that skip
+ * its stores / its LDS staging and produce WRONG output), "pp_trace" = device address of a timeline buffer
+ * (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown name or value. */
 int vtx_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------ LayerNorm

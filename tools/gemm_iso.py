@@ -9,7 +9,6 @@ import vtx
 from vtx import ops
 from kernel_bench import timeit
 vtx.set_option('gemm_nt', 'pp256')
-vtx.set_option('pp_skew', '0')
 N, K = 3072, 768
 for grid, M in ((8, 2048), (64, 2048 * 8), (256, 2048 * 32)):
     vtx.set_option('pp_grid', str(grid))

@@ -46,7 +46,6 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "pp_grid") == 0) { const int g = atoi(value); if (g < 8 || g > 4096 || g % 8) return VTX_EINVAL; o.pp_grid = g; return VTX_OK; }
   if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }
   if (strcmp(name, "pp_epi") == 0) { o.pp_epi = atoi(value); return VTX_OK; }
-  if (strcmp(name, "pp_skew") == 0) { o.pp_skew = (float)atof(value); return VTX_OK; }
   if (strcmp(name, "pp_trace") == 0) { o.pp_trace = strtoull(value, nullptr, 0); return VTX_OK; }
   return VTX_EINVAL;
 }
@@ -56,7 +55,7 @@ Options& options() {
     Options d;
     static const char* const env[][2] = {{"VTX_GEMM_NT", "gemm_nt"}, {"VTX_GEMM_TN", "gemm_tn"}, {"VTX_GEMM_NODMA", "gemm_nodma"},
                                          {"VTX_TN_SAFE", "tn_safe"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
-                                         {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"}, {"VTX_GEMM_PP_SKEW", "pp_skew"}};
+                                         {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"}};
     for (const auto& e : env) {
       const char* v = getenv(e[0]);
       if (v && *v) set_option(d, e[1], v);       // an unparsable value keeps the default

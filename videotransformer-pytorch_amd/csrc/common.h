@@ -142,8 +142,7 @@ struct Options {
   int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
   int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
   int pp_cg = 0;             // VTX_GEMM_PP_CG: column tiles per group (0: from K)
-  int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing of the batched one)
-  float pp_skew = 1.0f;      // VTX_GEMM_PP_SKEW: start-skew scale of the persistent NT GEMM
+  int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing); 2 / 3 = diagnostics: no stores / no staging
   unsigned long long pp_trace = 0;   // device address of a long long[256][8][8] timeline buffer (tools/pp_timeline.py), 0 = off
 };
 Options& options();

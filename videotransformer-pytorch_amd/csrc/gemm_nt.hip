@@ -373,7 +373,7 @@ __device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory
 template <bool EPI2, bool HAS_PRE, bool HAS_SC>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
-    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int tile_ticks, int CG, int* __restrict__ tile_ctr,
+    const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int CG, int* __restrict__ tile_ctr,
     long long* __restrict__ trace, int dbg, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
@@ -436,20 +436,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     if (tid == 0) v = atomicAdd(my_ctr, 1);
     return publish(v);
   };
-  // De-synchronise the CUs.  Every tile takes the same time, so all 256 workgroups would reach their
-  // epilogues together and share HBM's write bandwidth for the 128-KB C tiles (measured: the stores
-  // then cost their full HBM time, ~10 us per tile, un-overlapped).  The last round of tiles is
-  // partial (frac = xcount/per - floor): spread the start times over that slack, uniformly by slot.
-  {
-    const int nfull = xcount % per;              // tiles of the partial round (0: no slack, use half a tile)
-    const long slack = nfull ? (long)tile_ticks * (per - nfull) / per : tile_ticks / 2;
-    if (tile_ticks > 0 && per > 1) {
-      const long wait = slack * slot / per;
-      const long t0 = __builtin_amdgcn_s_memrealtime();
-      while ((long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-  }
-
   const bf16raw* src[4][2];                      // region kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
   int m0 = 0, n0 = 0;
   auto set_tile = [&](int t) {                  // t = local tile index of this XCD
@@ -766,8 +752,6 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
     attr_set = true;
   }
   const int tiles_m = cdiv(d->M, PP_BM), tiles_n = cdiv(d->N, PP_BN);
-  // estimated time of one tile in 10-ns ticks of the constant 100 MHz clock (1.5 us per K tile + 6 us)
-  const int tile_ticks = (int)(cfg.pp_skew * (150 * (d->K / PP_BK) + 600));
   // column tiles per group (tools/gemm_cg.py, M = 100352: 1 is 15 % slower at N = 3072, 3..8 are within noise;
   // K = 3072 wants >= 3): about 6 MB of weight panels, between 3 and 6 tiles
   int cg = cfg.pp_cg ? cfg.pp_cg : (int)(6291456L / (512L * d->K));
@@ -775,7 +759,7 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   if (!cfg.pp_cg && cg > 6) cg = 6;
   if (cg < 1) cg = 1;
   hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
-                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, tile_ticks, cg,
+                     (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, cg,
                      (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, ep);
   return check_launch("gemm_nt_pp");
 }

@@ -230,8 +230,10 @@ static int ln_blocks(int rows) {
 }
 // backward keeps per-block partial sums of dgamma/dbeta: fewer, fatter blocks
 static int ln_bwd_blocks(int rows) {
+  // 106 VGPRs -> 4 waves per SIMD -> 4 resident workgroups per CU: 1024 workgroups fill the chip in one round, and
+  // every extra one only adds a [2][D] partial row for reduce_partials to read
   int b = cdiv(rows, LN_WAVES * 4);
-  return b > 2048 ? 2048 : (b < 1 ? 1 : b);
+  return b > 1024 ? 1024 : (b < 1 ? 1 : b);
 }
 
 template <typename T>
