@@ -875,6 +875,11 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_f32_kernel(
 
 }  // namespace vtx
 
+namespace vtx {
+int launch_gemm_nt_w4(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st);
+int launch_gemm_nt_dual(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st);
+}
+
 using namespace vtx;
 
 extern "C" size_t vtx_gemm_nt_workspace(void) { return 9 * 64; }   // 8 per-XCD tile counters + 1 check-out counter, one 64-B line each
@@ -925,9 +930,11 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
     // the ping-pong kernel prefetches the residual and the GELU' input into the same registers, and keeps its
     // tile counters in the caller's workspace
     const bool pp_ok = dma_ok && nkt >= 2 && !(d->R && d->dgelu_in) && d->workspace && d->ws_bytes >= vtx_gemm_nt_workspace();
-    if (variant == NT_PP256 && pp_ok) return launch_pp(d, ep, st);
+    if (variant == NT_W4 && pp_ok && d->K % 32 == 0 && d->K >= 128) return launch_gemm_nt_w4(d, ep, st);
+    if (variant == NT_DUAL && pp_ok && d->K % 32 == 0 && d->K >= 128) return launch_gemm_nt_dual(d, ep, st);
+    if ((variant == NT_PP256 || variant == NT_W4 || variant == NT_DUAL) && pp_ok) return launch_pp(d, ep, st);
     if (dma_ok && nkt >= 3 && (variant == NT_RING256X3)) return launch_ring<4, 3, 64>(d, ep, st);
-    if (dma_ok && nkt >= 3 && (variant == NT_RING256X3K32 || variant == NT_PP256)) return launch_ring<4, 3, 32>(d, ep, st);
+    if (dma_ok && nkt >= 3 && (variant == NT_RING256X3K32 || variant == NT_PP256 || variant == NT_W4 || variant == NT_DUAL)) return launch_ring<4, 3, 32>(d, ep, st);
     if (dma_ok && nkt >= 3 && variant == NT_RING256X4K32) return launch_ring<4, 4, 32>(d, ep, st);
     if (dma_ok && nkt >= 3 && variant == NT_RING128X3) return launch_ring<2, 3, 64>(d, ep, st);
     if (dma_ok && nkt >= 3 && variant == NT_RING128X4K32) return launch_ring<2, 4, 32>(d, ep, st);
