@@ -40,7 +40,7 @@ def main():
     vtx.set_option('gemm_nt', 'pp256')
     for _ in range(3):
         ops.gemm_nt(A, W, C, M, N, K, **kw)
-    trace = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+    trace = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
     vtx.set_option('pp_trace', str(trace.data_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -48,7 +48,8 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     vtx.set_option('pp_trace', '0')
-    t = trace.cpu().reshape(256, 8, 8).double() * 0.01          # us
+    raw = trace.cpu().reshape(256, 8, 16).double()
+    t = raw[:, :, :8] * 0.01                                     # us
     print(f'M={M} N={N} K={K} {kind}: launch {e0.elapsed_time(e1) * 1e3:.1f} us, {2.0 * M * N * K / e0.elapsed_time(e1) / 1e9:.0f} TF/s')
     valid = (t[:, :, 0] > 0) & (t[:, :, 7] > 0)
     ntiles = valid.sum(1)
@@ -65,6 +66,9 @@ def main():
             print(f'  {SEG[s]:45s} mean {sel.mean():7.2f}  p50 {sel.median():7.2f}  p90 {sel.quantile(0.9):7.2f}  max {sel.max():7.2f}')
     whole = (t[:, 1:, 0] - t[:, :-1, 0])[valid[:, 1:] & valid[:, :-1]]
     print(f'  tile period (top to top)                      mean {whole.mean():7.2f}  p50 {whole.median():7.2f}  p90 {whole.quantile(0.9):7.2f}')
+    cyc = (raw[:, :, 9] - raw[:, :, 8])[valid]
+    ml = (t[:, :, 2] - t[:, :, 1])[valid]
+    print(f'  main loop: {cyc.mean() / (K // 64):.0f} shader cycles per 64-deep K tile (MFMA floor 2048) at {cyc.mean() / ml.mean():.0f} MHz')
     start = t[:, 0, 0][t[:, 0, 0] > 0]
     print(f'  first-tile start spread across workgroups: {start.max() - start.min():.1f} us')
 

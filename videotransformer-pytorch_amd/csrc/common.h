@@ -132,7 +132,7 @@ __device__ inline float gelu_erf_grad(float x) {
 // ---- tuning / diagnostic switches ----------------------------------------------------
 // Process-wide, set through vtx_set_option() (initial values come from the VTX_* environment
 // variables, read ONCE when the library is first used -- never on the launch path).
-enum { NT_AUTO = 0, NT_PP256, NT_DMA2, NT_RING128X3, NT_RING128X4K32, NT_RING256X3, NT_RING256X3K32, NT_RING256X4K32, NT_W4, NT_DUAL };
+enum { NT_AUTO = 0, NT_PP256, NT_DMA2, NT_RING128X3, NT_RING128X4K32, NT_RING256X3, NT_RING256X3K32, NT_RING256X4K32 };
 enum { TN_AUTO = 0, TN_PP256, TN_RING, TN_DMA2 };
 struct Options {
   int gemm_nt = NT_AUTO;     // VTX_GEMM_NT: kernel family override of vtx_gemm_nt (bf16)
@@ -150,9 +150,11 @@ Options& options();
 // ---- host-side error plumbing --------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
-// out[n] (+)= scale * sum_s part[s*stride + n]; columns >= split optionally go to out2 (ln.hip)
+// out[n] (+)= scale * sum_s part[s*stride + n]; columns >= split optionally go to out2, summed over `fold` copies per
+// slab (ln.hip)
 int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out, int accumulate, float scale,
-                           hipStream_t st, float* out2 = nullptr, long split = 0, int accumulate2 = 0);
+                           hipStream_t st, float* out2 = nullptr, long split = 0, int accumulate2 = 0, int fold = 1,
+                           long fold_stride = 0);
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define VTX_REQUIRE(cond, code, ...)        \

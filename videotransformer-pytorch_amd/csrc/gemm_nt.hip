@@ -382,11 +382,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   const int wr = wave >> 2, wc = wave & 3;
   float* stg = reinterpret_cast<float*>(smem + PP_RING_BYTES) + wave * 16 * PP_STG_LD;
   const int nk = K / PP_BK;
-  // timeline of the first 8 tiles of every workgroup (tools/pp_timeline.py): 100 MHz ticks at 8 points per tile
+  // timeline of the first 8 tiles of every workgroup (tools/pp_timeline.py): 16 words per tile -- 100 MHz ticks at 8
+  // points, and the shader-clock counter at points 1 and 2 (main loop start / end: cycles / time = the clock the chip
+  // sustains inside the main loop) in words 8 and 9
   int trace_tile = 0;
   auto stamp = [&](int e) {
-    if (trace != nullptr && tid == 0 && trace_tile < 8)
-      trace[((long)blockIdx.x * 8 + trace_tile) * 8 + e] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (trace != nullptr && tid == 0 && trace_tile < 8) {
+      long long* slot = trace + ((long)blockIdx.x * 8 + trace_tile) * 16;
+      slot[e] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (e == 1 || e == 2) slot[7 + e] = (long long)__builtin_amdgcn_s_memtime();
+    }
   };
 
   // Tile walk.  XCD x owns the row tiles [rlo, rhi) for ALL column tiles and walks them column-group
@@ -875,10 +880,6 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_f32_kernel(
 
 }  // namespace vtx
 
-namespace vtx {
-int launch_gemm_nt_w4(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st);
-int launch_gemm_nt_dual(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st);
-}
 
 using namespace vtx;
 
@@ -930,11 +931,9 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
     // the ping-pong kernel prefetches the residual and the GELU' input into the same registers, and keeps its
     // tile counters in the caller's workspace
     const bool pp_ok = dma_ok && nkt >= 2 && !(d->R && d->dgelu_in) && d->workspace && d->ws_bytes >= vtx_gemm_nt_workspace();
-    if (variant == NT_W4 && pp_ok && d->K % 32 == 0 && d->K >= 128) return launch_gemm_nt_w4(d, ep, st);
-    if (variant == NT_DUAL && pp_ok && d->K % 32 == 0 && d->K >= 128) return launch_gemm_nt_dual(d, ep, st);
-    if ((variant == NT_PP256 || variant == NT_W4 || variant == NT_DUAL) && pp_ok) return launch_pp(d, ep, st);
+    if (variant == NT_PP256 && pp_ok) return launch_pp(d, ep, st);
     if (dma_ok && nkt >= 3 && (variant == NT_RING256X3)) return launch_ring<4, 3, 64>(d, ep, st);
-    if (dma_ok && nkt >= 3 && (variant == NT_RING256X3K32 || variant == NT_PP256 || variant == NT_W4 || variant == NT_DUAL)) return launch_ring<4, 3, 32>(d, ep, st);
+    if (dma_ok && nkt >= 3 && (variant == NT_RING256X3K32 || variant == NT_PP256)) return launch_ring<4, 3, 32>(d, ep, st);
     if (dma_ok && nkt >= 3 && variant == NT_RING256X4K32) return launch_ring<4, 4, 32>(d, ep, st);
     if (dma_ok && nkt >= 3 && variant == NT_RING128X3) return launch_ring<2, 3, 64>(d, ep, st);
     if (dma_ok && nkt >= 3 && variant == NT_RING128X4K32) return launch_ring<2, 4, 32>(d, ep, st);

@@ -32,6 +32,7 @@ struct TnOut {
   float* slab; long slab_stride;  // [splits][N1*N2]
   int N1, N2;
   float* cslab;                   // [splits][N1] column sums of A (bias gradient), or nullptr
+  int cs_fold;                    // ring / ping-pong kernels: [splits][cs_fold][N1], copy t2 = the K tiles kt % tiles2 == t2
 };
 
 __device__ inline void tn_store(const TnOut& o, const float* stage, int split, int r_base, int c_base, int lane) {
@@ -338,6 +339,17 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_tn_bf16_dma_kernel(
 // Mirror of gemm_nt's <4,3,32> ring: 8 waves (4x2, each 64x64), 32 token rows per stage
 // (A [32][256] + B [32][128] bf16 = 24 KB), 3 stages = 72 KB -> two workgroups per CU.  Chunk
 // swizzle ^((row&3)<<2) on the DMA source side keeps the transpose reads conflict free.
+// Transpose reads are issued as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read it emits itself
+// while LDS-DMA requests are outstanding (it cannot prove the read does not alias the DMA destination), which drains
+// the whole lookahead at the top of every load section -- measured: DMA-only 483 us + MFMA-only 486 us = 1047 us for
+// 150528x768x3072 instead of overlapping.  The price: the compiler does not count these reads either, so every load
+// section ends in an explicit lgkmcnt(0) and the fragments are pinned behind it (TP_PIN) before the MFMAs use them.
+typedef __attribute__((address_space(3))) char tn_lds_char;
+template <int OFF> __device__ inline s16x4 tn_tr_read(unsigned addr) {
+  s16x4 d;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+  return d;
+}
 template <int N> __device__ inline void tn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int TR_BKM = 32, TR_NBUF = 3, TR_A_LD = 256, TR_B_LD = 128;
 constexpr int TR_STAGE = TR_BKM * (TR_A_LD + TR_B_LD);      // elements per stage
@@ -422,7 +434,11 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
     a_off[i] = tr_row * TR_A_LD + (((ca >> 3) ^ tr_sw) << 3) + (ca & 7);
     b_off[i] = tr_row * TR_B_LD + (((cb >> 3) ^ tr_sw) << 3) + (cb & 7);
   }
-  const bool do_cs = out.cslab != nullptr && t2 == 0;
+  const unsigned lds_b = (unsigned)(unsigned long)(tn_lds_char*)smem;
+  // bias gradient: the tiles2 workgroups of a row tile read the same A rows; each sums the stages ti % tiles2 == t2
+  // into its own partial copy (a single column tile doing all of it finishes last and holds the launch: 12 % on 3072x768)
+  const bool want_cs = out.cslab != nullptr;
+  int cs_next = t2;
   const int cs_row = tid >> 5, cs_pc = tid & 31;                  // rows cs_row, cs_row+16 (same row&3)
   const int cs_chunk = cs_pc ^ ((cs_row & 3) << 2);
   float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -447,44 +463,42 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
       int nbuf = buf + TR_NBUF - 1; if (nbuf >= TR_NBUF) nbuf -= TR_NBUF;
       if (nxt < n_full) stage(nbuf, m_begin + nxt * TR_BKM);
     }
-    const bf16raw* Ab = ring + buf * TR_STAGE;
-    const bf16raw* Bb = Ab + TR_BKM * TR_A_LD;
+    const unsigned stage_b = lds_b + 2u * (unsigned)(buf * TR_STAGE);
+    const bool do_cs = want_cs && ti == cs_next;
     if (do_cs) {
+      cs_next += tiles2;
+      u32x4 v_[2];
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v_[0]), "=&v"(v_[1]) : "v"(stage_b + 2u * (cs_row * TR_A_LD + cs_pc * 8)) : "memory");
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const uint4 v = *reinterpret_cast<const uint4*>(Ab + (cs_row + 16 * it) * TR_A_LD + cs_pc * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          csum[2 * j] += __uint_as_float(w[j] << 16);
-          csum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+          csum[2 * j] += __uint_as_float(v_[it][j] << 16);
+          csum[2 * j + 1] += __uint_as_float(v_[it][j] & 0xffff0000u);
         }
-      }
     }
-#pragma unroll
-    for (int ks = 0; ks < TR_BKM / 16; ++ks) {
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bf16raw* pa = Ab + ks * 16 * TR_A_LD + a_off[i];
-        const bf16raw* pb = Bb + ks * 16 * TR_B_LD + b_off[i];
-        union { bf16x8 v; s16x4 h[2]; } ua, ub;
-        ua.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
-        ua.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * TR_A_LD));
-        ub.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
-        ub.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * TR_B_LD));
-        af[i] = ua.v; bfr[i] = ub.v;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    // per 16-deep k step: 8 transpose reads (inline asm: see tn_tr_read), an explicit wait that pins the fragments, 4 MFMAs
+#define TR_KSTEP(KA_, KB_)                                                                               \
+    {                                                                                                    \
+      bf16x8 af[2], bfr[2];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+        const unsigned pa = stage_b + 2u * a_off[i], pb = stage_b + 2u * (TR_BKM * TR_A_LD + b_off[i]);  \
+        union { bf16x8 v; s16x4 h[2]; } u_;                                                              \
+        u_.h[0] = tn_tr_read<KA_>(pa); u_.h[1] = tn_tr_read<KA_ + 2048>(pa); af[i] = u_.v;               \
+        u_.h[0] = tn_tr_read<KB_>(pb); u_.h[1] = tn_tr_read<KB_ + 1024>(pb); bfr[i] = u_.v;              \
+      }                                                                                                  \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]));       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);        \
     }
+    TR_KSTEP(0, 0)
+    TR_KSTEP(8192, 4096)
+#undef TR_KSTEP
     if (++buf == TR_NBUF) buf = 0;
   }
   __syncthreads();
-  if (do_cs) {
+  if (want_cs) {
     float* red = reinterpret_cast<float*>(smem);            // [16][256]
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[cs_row * 256 + cs_chunk * 8 + j] = csum[j];
@@ -493,7 +507,7 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
       float a = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a += red[r * 256 + tid];
-      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
+      out.cslab[(long)split * out.slab_stride + (long)t2 * out.N1 + r0 + tid] = a;
     }
     __syncthreads();
   }
@@ -529,8 +543,10 @@ __global__ __launch_bounds__(512, 4) void gemm_tn_bf16_ring_kernel(
 // Same region-wise lookahead / vmcnt / barrier protocol as gemm_nt_bf16_pp_kernel (see there).
 // A ragged last tile is fetched with clamped row indices and the rows beyond the span are zeroed in
 // LDS by the wave that fetched them (right after its vmcnt wait, before the publishing barrier).
-// Bias gradient: workgroups of column tile 0 also sum the A regions over the token rows (two
-// ds_read_b128 + 16 adds per thread and region, in the load sections).
+// Bias gradient: every workgroup sums the A regions over the token rows (two ds_read_b128 + 16 adds per thread and
+// region, in the load sections) of the K tiles kt % tiles2 == t2 -- the tiles2 workgroups of one row tile read the same
+// A rows, so each takes a 1/tiles2 share into its own partial copy instead of column tile 0 doing it all and finishing
+// last (one resident round: the launch ends with its slowest workgroup; measured 8 % on 768x3072).
 constexpr int TP_BK = 64, TP_THREADS = 512;
 constexpr int TP_REGION = TP_BK * 128;           // elements
 constexpr int TP_BUF = 4 * TP_REGION;            // [A0 | B0 | B1 | A1]
@@ -635,37 +651,46 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     const int cc = (wc & 1) * 32 + cl;                       // column inside sub-block wc>>1
     fb_off = (wc >> 1) * 4096 + tr_row * 64 + (((cc >> 3) ^ tr_sw) << 3) + (cc & 7);
   }
+  const unsigned lds_b = (unsigned)(unsigned long)(tn_lds_char*)smem;
+  const unsigned fa_addr[2] = {lds_b + 2u * fa_off[0], lds_b + 2u * fa_off[1]}, fb_addr = lds_b + 2u * fb_off;
   // column sums: thread -> sub-block tid>>8, physical chunk tid&7 of rows (tid>>3)&31 and +32
-  const bool do_cs = out.cslab != nullptr && t2 == 0;
+  const bool want_cs = out.cslab != nullptr;
+  bool do_cs = false;                              // this K tile is one of ours
+  int cs_next = t2;                                // next K tile whose A regions this workgroup sums
   const int cs_sub = tid >> 8, cs_row = (tid >> 3) & 31, cs_pc = tid & 7;
   float cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned cs_addr = lds_b + 2u * (cs_sub * 4096 + cs_row * 64 + cs_pc * 8);
 #define TP_COLSUM(buf_, kind_, cs_)                                                                      \
   if (do_cs) {                                                                                           \
-    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                   \
-      const uint4 v = *reinterpret_cast<const uint4*>(lds + (buf_) * TP_BUF + (kind_) * TP_REGION +      \
-                                                      cs_sub * 4096 + (cs_row + 32 * it) * 64 + cs_pc * 8); \
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};                                                        \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
-        cs_[2 * j] += __uint_as_float(w[j] << 16);                                                       \
-        cs_[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);                                           \
-      }                                                                                                  \
+    u32x4 v_[2];                                                                                         \
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\ts_waitcnt lgkmcnt(0)"        \
+                 : "=&v"(v_[0]), "=&v"(v_[1]) : "v"(cs_addr + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION)) : "memory"); \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) _Pragma("unroll") for (int j = 0; j < 4; ++j) {     \
+      cs_[2 * j] += __uint_as_float(v_[it][j] << 16);                                                    \
+      cs_[2 * j + 1] += __uint_as_float(v_[it][j] & 0xffff0000u);                                        \
     }                                                                                                    \
   }
-#define TP_TR(ptr_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr_))
 #define TP_READ_A(buf_, kind_)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {       \
-    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 64 + fa_off[i];          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+    const unsigned a_ = fa_addr[i] + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION);                       \
     union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
-    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 64);                                                  \
-    fa[i][ks] = u_.v;                                                                                    \
+    u_.h[0] = tn_tr_read<0>(a_);    u_.h[1] = tn_tr_read<512>(a_);         fa[i][0] = u_.v;              \
+    u_.h[0] = tn_tr_read<2048>(a_); u_.h[1] = tn_tr_read<2048 + 512>(a_);  fa[i][1] = u_.v;              \
+    u_.h[0] = tn_tr_read<4096>(a_); u_.h[1] = tn_tr_read<4096 + 512>(a_);  fa[i][2] = u_.v;              \
+    u_.h[0] = tn_tr_read<6144>(a_); u_.h[1] = tn_tr_read<6144 + 512>(a_);  fa[i][3] = u_.v;              \
   }
 #define TP_READ_B(buf_, kind_, fb_)                                                                      \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
-    const bf16raw* p_ = lds + (buf_) * TP_BUF + (kind_) * TP_REGION + ks * 16 * 64 + fb_off;             \
+  {                                                                                                      \
+    const unsigned a_ = fb_addr + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION);                          \
     union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
-    u_.h[0] = TP_TR(p_); u_.h[1] = TP_TR(p_ + 4 * 64);                                                  \
-    fb_[ks] = u_.v;                                                                                      \
+    u_.h[0] = tn_tr_read<0>(a_);    u_.h[1] = tn_tr_read<512>(a_);         fb_[0] = u_.v;                \
+    u_.h[0] = tn_tr_read<2048>(a_); u_.h[1] = tn_tr_read<2048 + 512>(a_);  fb_[1] = u_.v;                \
+    u_.h[0] = tn_tr_read<4096>(a_); u_.h[1] = tn_tr_read<4096 + 512>(a_);  fb_[2] = u_.v;                \
+    u_.h[0] = tn_tr_read<6144>(a_); u_.h[1] = tn_tr_read<6144 + 512>(a_);  fb_[3] = u_.v;                \
   }
+#define TP_PIN_A() asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),      \
+                                     "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]))
+#define TP_PIN_B(fb_) asm volatile("" : "+v"(fb_[0]), "+v"(fb_[1]), "+v"(fb_[2]), "+v"(fb_[3]))
 #define TP_MMA(i0_, j_, fb_, ISSUE_)                                                                     \
   __builtin_amdgcn_s_setprio(1);                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
@@ -687,6 +712,8 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    do_cs = want_cs && kt == cs_next;
+    if (do_cs) cs_next += tiles2;
     // (DMA requests are issued in the shadow of the MFMAs, see gemm_nt_bf16_pp_kernel)
     // P1: reads A0, B0; P2 will read B1(kt)
     TP_READ_A(buf, 0);
@@ -695,6 +722,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<2>();
     tp_lgkm0();
     TP_BAR();
+    TP_PIN_A(); TP_PIN_B(fb0);
     TP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));
     TP_BAR();
     // P2: reads B1; P3 will read A1(kt)
@@ -702,6 +730,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<0>();
     tp_lgkm0();
     TP_BAR();
+    TP_PIN_B(fb1);
     TP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));
     TP_BAR();
     // P3: reads A1
@@ -709,6 +738,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     TP_COLSUM(buf, 3, cs1);
     tp_lgkm0();
     TP_BAR();
+    TP_PIN_A();
     TP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));
     TP_BAR();
     // P4: no reads; P1 of the next tile will read A0(kt+1), B0(kt+1)
@@ -723,12 +753,13 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   }
   if (wr == 0) TP_BAR();
 #undef TP_COLSUM
-#undef TP_TR
+#undef TP_PIN_A
+#undef TP_PIN_B
 #undef TP_READ_A
 #undef TP_READ_B
 #undef TP_MMA
 #undef TP_BAR
-  if (do_cs) {
+  if (want_cs) {
     // logical chunk of this thread = cs_pc ^ (((cs_row>>1)&1)<<2) (rows cs_row, cs_row+32 share bit 1);
     // sub-block s of A0 = tile columns s*128 + [0,64), of A1 = s*128 + 64 + [0,64)
     float* red = reinterpret_cast<float*>(smem);            // [32][256] floats = 32 KB (ring is free)
@@ -743,7 +774,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
       float a = 0.f;
 #pragma unroll
       for (int r = 0; r < 32; ++r) a += red[r * 256 + tid];
-      out.cslab[(long)split * out.slab_stride + r0 + tid] = a;
+      out.cslab[(long)split * out.slab_stride + (long)t2 * out.N1 + r0 + tid] = a;
     }
     __syncthreads();
   }
@@ -937,7 +968,8 @@ using namespace vtx;
 extern "C" size_t vtx_gemm_tn_workspace(int M, int N1, int N2) {
   size_t s = (size_t)tn_splits(M, N1, N2);
   if (tp_eligible(M, N1, N2) && (size_t)tp_splits(M, N1, N2) > s) s = (size_t)tp_splits(M, N1, N2);
-  return s * (size_t)N1 * (size_t)N2 * sizeof(float) + s * (size_t)N1 * sizeof(float);   // slabs + column-sum slabs
+  // slabs + column-sum slabs (the ring and ping-pong kernels keep one partial copy per column tile)
+  return s * (size_t)N1 * (size_t)N2 * sizeof(float) + s * (size_t)N1 * (size_t)cdiv(N2, 128) * sizeof(float);
 }
 
 extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
@@ -961,7 +993,7 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   // per-split slab = [N1*N2 weight partials | N1 column-sum partials]
   const long w_elems = (long)d->N1 * d->N2;
   out.slab = (float*)d->workspace; out.slab_stride = w_elems + d->N1; out.N1 = d->N1; out.N2 = d->N2;
-  out.cslab = d->colsum ? out.slab + w_elems : nullptr;
+  out.cslab = d->colsum ? out.slab + w_elems : nullptr; out.cs_fold = 1;
   dim3 grid(tiles1 * tiles2 * splits), block(NT_THREADS);
   hipStream_t st = as_stream(stream);
   if (d->dtype == VTX_BF16) {
@@ -970,11 +1002,12 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     const Options& o = options();
     const bool safe = o.tn_safe != 0, nodma = o.gemm_nodma != 0;
     const bool want_ring = o.gemm_tn != TN_DMA2 && d->M >= 1024;   // "pp256" falls back to the ring when ineligible
-    // Default is the 256x128 ring (2 workgroups per CU): with the XCD-aware split-major order it is as fast
-    // or faster than the 256x256 ping-pong kernel on every weight-gradient shape of the model
-    // (tools/gemm_sweep.py 100352: 2304x768 475 vs 513 us, 768x3072 648 vs 666 us, 768x768 202 vs 195 us);
-    // both are bound by the CU's L1 miss capacity.  VTX_GEMM_TN=pp256 selects the ping-pong kernel.
-    const bool want_pp = o.gemm_tn == TN_PP256 && tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
+    // Default: the 256x128 ring (2 workgroups per CU), except for wide-B shapes (N2 >= 4 N1: the fc2 weight gradient
+    // 768x3072), where the 256x256 ping-pong kernel's larger tile wins.  tools/tn_compare.py at M = 150528, with the fused
+    // bias-gradient sums, ring / ping-pong: 768x3072 974 / 850 us, 3072x768 791 / 858, 2304x768 603 / 672, 768x768 219 / 240.
+    // gemm_tn=pp256 / ring force one of them.
+    const bool pp_fits = tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
+    const bool want_pp = pp_fits && (o.gemm_tn == TN_PP256 || (o.gemm_tn == TN_AUTO && d->N2 >= 4 * d->N1));
     if (!safe && !nodma && want_pp) {
       const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
       const int s_p = tp_splits(d->M, d->N1, d->N2);
@@ -986,14 +1019,16 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
         attr_set_p = true;
       }
       if (m_per_p >= 2 * TP_BK) {
+        out.slab_stride = w_elems + (long)t2p * d->N1; out.cs_fold = t2p;
         hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(t1p * t2p * s_eff), dim3(TP_THREADS), TP_LDS_BYTES, st, d->M, m_per_p,
                            (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out);
         int rc_p = check_launch("gemm_tn_pp");
         if (rc_p) return rc_p;
         if (!d->colsum) return launch_reduce_partials(out.slab, s_eff, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
         return launch_reduce_partials(out.slab, s_eff, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
-                                      d->colsum, w_elems, d->colsum_accumulate);
+                                      d->colsum, w_elems, d->colsum_accumulate, t2p, d->N1);
       }
+      out.slab_stride = w_elems + d->N1; out.cs_fold = 1;
     }
     if (!safe && !nodma && want_ring) {
       const int tiles1r = cdiv(d->N1, 256);
@@ -1012,13 +1047,14 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
         attr_set = true;
       }
+      out.slab_stride = w_elems + (long)tiles2 * d->N1; out.cs_fold = tiles2;
       hipLaunchKernelGGL(gemm_tn_bf16_ring_kernel, dim3(tiles1r * tiles2 * s_r), dim3(512), lds_r, st, d->M, m_per_r,
                          (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, tiles2, tiles1r * tiles2, out);
       int rc_r = check_launch("gemm_tn_ring");
       if (rc_r) return rc_r;
       if (!d->colsum) return launch_reduce_partials(out.slab, s_r, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
       return launch_reduce_partials(out.slab, s_r, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
-                                    d->colsum, w_elems, d->colsum_accumulate);
+                                    d->colsum, w_elems, d->colsum_accumulate, tiles2, d->N1);
     } else if (!safe && !nodma) {
       const size_t need_d = (size_t)4 * TN_BKM * TN_DLD * 2;
       const size_t lds_d = STAGE_BYTES > need_d ? STAGE_BYTES : need_d;

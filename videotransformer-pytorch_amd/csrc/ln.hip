@@ -186,15 +186,18 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(
 
 // out[n] (+)= scale * sum_s part[s*stride + n], n < N.  64 columns x 4 slab lanes per block:
 // coalesced 256-B row segments, independent loads in flight, fixed summation order.
-// Columns n >= split (when out2 != nullptr) go to out2[n - split] (two results, one launch).
+// Columns n >= split (when out2 != nullptr) go to out2[n - split] (two results, one launch); with fold > 1 every slab
+// holds `fold` partial copies of those columns, fold_stride apart, which are summed too (slab-major, copy-minor order).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nslabs, long stride,
                                                               long N, float* __restrict__ out, int accumulate, float scale,
-                                                              float* __restrict__ out2, long split, int accumulate2) {
+                                                              float* __restrict__ out2, long split, int accumulate2,
+                                                              int fold, long fold_stride) {
   __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
   const long n = (long)blockIdx.x * 64 + cx;
+  const bool tail = out2 != nullptr && n >= split;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (n < N) {
+  if (n < N && !(tail && fold > 1)) {
     int s = sy;
     for (; s + 12 < nslabs; s += 16) {
       a0 += part[(long)s * stride + n];
@@ -203,12 +206,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
       a3 += part[(long)(s + 12) * stride + n];
     }
     for (; s < nslabs; s += 4) a0 += part[(long)s * stride + n];
+  } else if (n < N) {
+    for (int v = sy; v < nslabs * fold; v += 4) {
+      const int s = v / fold, f = v - s * fold;
+      a0 += part[(long)s * stride + (long)f * fold_stride + n];
+    }
   }
   red[sy][cx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sy == 0 && n < N) {
     const float a = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * scale;
-    if (out2 != nullptr && n >= split) {
+    if (tail) {
       float* o = out2 + (n - split);
       *o = accumulate2 ? *o + a : a;
     } else {
@@ -218,9 +226,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
-                           int accumulate, float scale, hipStream_t st, float* out2, long split, int accumulate2) {
+                           int accumulate, float scale, hipStream_t st, float* out2, long split, int accumulate2,
+                           int fold, long fold_stride) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, part, nslabs,
-                     stride, N, out, accumulate, scale, out2, split, accumulate2);
+                     stride, N, out, accumulate, scale, out2, split, accumulate2, fold, fold_stride);
   return check_launch("reduce_partials");
 }
 
