@@ -97,75 +97,122 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
   }
 }
 
+// raw 4-element vectors (kept packed while a prefetched row waits in registers)
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16raw> { typedef uint2 type; };
+__device__ inline void unpack4(const float4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+__device__ inline void unpack4(const uint2& r, float (&v)[4]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+
 // Backward.  Each wave walks rows r = w, w + W, ...; per-lane column partials of
 // dgamma/dbeta stay in registers, are combined across the block's 4 waves in
 // LDS and written to part[block][2][D]; reduce_partials_kernel finishes.
-template <typename T, int NCH>
-__global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(
+// The x / dy / residual-gradient segments of the NEXT row are requested before the current row is reduced (one memory
+// round trip per row instead of two -- the residual used to be fetched after the reductions -- and overlapped with the
+// arithmetic): the kernel is bound by bytes in flight per wave, not by arithmetic.
+// FULL: D == 256 NCH (no column predicate); RES: a residual gradient is added.  Both are compile-time so that the row loop
+// is branch free -- with exec-masked loads in it hipcc falls back to vmcnt(0) waits and the prefetch is lost.
+template <typename T, int NCH, bool FULL, bool RES>
+__global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && NCH <= 3) ? 3 : 1) void ln_bwd_kernel(
     int rows, int D, const T* __restrict__ dy, long lddy, vtx_rowmap dymap,
     const T* __restrict__ x, long ldx, vtx_rowmap xmap, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ dres,
     T* __restrict__ dx, long lddx, float* __restrict__ part) {
+  typedef typename Raw4<T>::type raw_t;
   __shared__ float red[LN_WAVES][2][NCH * 256];
+  __shared__ float gsm[NCH * 256];                 // gamma: read per row from LDS instead of held in 4*NCH registers
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const long total_waves = (long)gridDim.x * LN_WAVES;
   const float invD = 1.0f / (float)D;
-  float dg[NCH][4], db[NCH][4], gm[NCH][4];
+  for (int i = threadIdx.x; i < NCH * 256; i += LN_WAVES * 64) gsm[i] = i < D ? gamma[i] : 0.f;
+  __syncthreads();
+  float dg[NCH][4], db[NCH][4];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int col = 4 * (lane + 64 * c);
+  for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; gm[c][j] = (col < D) ? gamma[col + j] : 0.f; }
-  }
-  for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += total_waves) {
-    const long pr = map_row(xmap, r);
-    const T* xr = x + pr * ldx;
+    for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+  struct Row { raw_t x[NCH], dy[NCH], dr[NCH]; float mu, rs; long pr; };
+  auto fetch = [&](long r, Row& w) {
+    w.pr = map_row(xmap, r);
+    const T* xr = x + w.pr * ldx;
     const T* dyr = dy + map_row(dymap, r) * lddy;
-    const float mu = mean[r], rs = rstd[r];
-    float xh[NCH][4], g[NCH][4];
+    const T* drr = dres + w.pr * lddx;
+    w.mu = mean[r]; w.rs = rstd[r];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+        w.x[c] = *reinterpret_cast<const raw_t*>(xr + col);
+        w.dy[c] = *reinterpret_cast<const raw_t*>(dyr + col);
+        if (RES) w.dr[c] = *reinterpret_cast<const raw_t*>(drr + col);
+      }
+    }
+  };
+  // pass 1: row sums and the dgamma / dbeta partials; pass 2 recomputes xhat and g from the packed row (a few VALU ops
+  // per element, the kernel is HBM-bound) instead of keeping 8 NCH floats per row alive next to the second row
+  auto pass1 = [&](const Row& w, float& c1, float& c2) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
-      if (col < D) {
-        float xv[4], dv[4];
-        ld4<T>(xr + col, xv);
-        ld4<T>(dyr + col, dv);
+      if (FULL || col < D) {
+        float xv[4], dv[4], gm[4];
+        unpack4(w.x[c], xv);
+        unpack4(w.dy[c], dv);
+        unpack4(*reinterpret_cast<const float4*>(gsm + col), gm);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[c][j] = (xv[j] - mu) * rs;
-          g[c][j] = dv[j] * gm[c][j];
-          s1 += g[c][j];
-          s2 += g[c][j] * xh[c][j];
-          dg[c][j] += dv[j] * xh[c][j];
+          const float xh = (xv[j] - w.mu) * w.rs, g = dv[j] * gm[j];
+          s1 += g;
+          s2 += g * xh;
+          dg[c][j] += dv[j] * xh;
           db[c][j] += dv[j];
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { xh[c][j] = 0.f; g[c][j] = 0.f; }
       }
     }
-    const float c1 = wave_sum(s1) * invD;
-    const float c2 = wave_sum(s2) * invD;
-    T* dxr = dx + pr * lddx;
-    const T* drr = dres ? dres + pr * lddx : nullptr;
+    c1 = wave_sum(s1) * invD;
+    c2 = wave_sum(s2) * invD;
+  };
+  auto pass2 = [&](const Row& w, float c1, float c2) {
+    T* dxr = dx + w.pr * lddx;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
-      if (col < D) {
-        float o[4];
+      if (FULL || col < D) {
+        float xv[4], dv[4], gm[4], o[4];
+        unpack4(w.x[c], xv);
+        unpack4(w.dy[c], dv);
+        unpack4(*reinterpret_cast<const float4*>(gsm + col), gm);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rs * (g[c][j] - c1 - xh[c][j] * c2);
-        if (drr) {
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - w.mu) * w.rs, g = dv[j] * gm[j];
+          o[j] = w.rs * (g - c1 - xh * c2);
+        }
+        if (RES) {
           float rv[4];
-          ld4<T>(drr + col, rv);
+          unpack4(w.dr[c], rv);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += rv[j];
         }
         st4<T>(dxr + col, o);
       }
     }
+  };
+  // two rows per trip: both rows' x / dy / residual segments are requested before either is reduced
+  for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += 2 * total_waves) {
+    Row ra, rb;
+    const bool two = r + total_waves < rows;
+    fetch(r, ra);
+    fetch(two ? r + total_waves : r, rb);
+    float a1, a2, b1, b2;
+    pass1(ra, a1, a2);
+    if (two) pass1(rb, b1, b2);
+    pass2(ra, a1, a2);
+    if (two) pass2(rb, b1, b2);
   }
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -207,9 +254,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
     for (; s < nslabs; s += 4) a0 += part[(long)s * stride + n];
   } else if (n < N) {
-    for (int v = sy; v < nslabs * fold; v += 4) {
-      const int s = v / fold, f = v - s * fold;
-      a0 += part[(long)s * stride + (long)f * fold_stride + n];
+    // (slab, copy) pairs sy, sy+4, ... in slab-major order; four independent loads per round
+    const int total = nslabs * fold;
+    int v = sy, s = sy / fold, f = sy - (sy / fold) * fold;
+    auto next = [&]() { v += 4; f += 4; while (f >= fold) { f -= fold; ++s; } };
+    auto at = [&]() { return v < total ? part[(long)s * stride + (long)f * fold_stride + n] : 0.f; };
+    while (v < total) {
+      const float x0 = at(); next();
+      const float x1 = at(); next();
+      const float x2 = at(); next();
+      const float x3 = at(); next();
+      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
     }
   }
   red[sy][cx] = (a0 + a1) + (a2 + a3);
@@ -270,12 +325,29 @@ template <typename T>
 static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap, const void* x,
                     long ldx, vtx_rowmap xmap, const float* mean, const float* rstd,
                     const float* gamma, const void* dres, void* dx, long lddx, float* part,
-                    int nblocks, hipStream_t st) {
+                    int nblocks, int* launched, hipStream_t st) {
   const int nch = cdiv(D, 256);
-  dim3 g(nblocks), b(LN_WAVES * 64);
+  dim3 b(LN_WAVES * 64);
+  // one resident round: as many workgroups as the instantiation's occupancy holds (never more than the workspace rows)
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+#define LN_BWD_(N, F, R)                                                                           \
+  {                                                                                                \
+    static int per_cu = 0;                                                                         \
+    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_bwd_kernel<T, N, F, R>, LN_WAVES * 64, 0) \
+                        != hipSuccess || per_cu <= 0)) per_cu = 2;                                 \
+    dim3 g(nblocks < per_cu * n_cu ? nblocks : per_cu * n_cu);                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, N, F, R>), g, b, 0, st, rows, D, (const T*)dy, lddy, dymap, \
+                       (const T*)x, ldx, xmap, mean, rstd, gamma, (const T*)dres, (T*)dx, lddx, part); \
+    *launched = (int)g.x;                                                                          \
+  }
 #define LN_BWD(N)                                                                                  \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, N>), g, b, 0, st, rows, D, (const T*)dy, lddy, dymap,       \
-                     (const T*)x, ldx, xmap, mean, rstd, gamma, (const T*)dres, (T*)dx, lddx, part)
+  if (D == N * 256) { if (dres) LN_BWD_(N, true, true) else LN_BWD_(N, true, false) }              \
+  else { if (dres) LN_BWD_(N, false, true) else LN_BWD_(N, false, false) }
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -285,6 +357,7 @@ static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap
     default: LN_BWD(8); break;
   }
 #undef LN_BWD
+#undef LN_BWD_
   return check_launch("layernorm_bwd");
 }
 
@@ -327,14 +400,14 @@ extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, lon
   const int nb = ln_bwd_blocks(rows);
   float* part = (float*)workspace;
   hipStream_t st = as_stream(stream);
-  int rc;
+  int rc, launched = nb;
   if (dtype == VTX_F32)
-    rc = ln_bwd_t<float>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, st);
+    rc = ln_bwd_t<float>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, &launched, st);
   else if (dtype == VTX_BF16)
-    rc = ln_bwd_t<bf16raw>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, st);
+    rc = ln_bwd_t<bf16raw>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, &launched, st);
   else
     VTX_REQUIRE(false, VTX_EINVAL, "layernorm_bwd: bad dtype %d", dtype);
   if (rc) return rc;
   // part layout: [block][2][D] -> dgamma += sum_b part[b][0], dbeta += sum_b part[b][1] (one launch)
-  return launch_reduce_partials(part, nb, 2L * D, 2L * D, dgamma, 1, 1.0f, st, dbeta, D, 1);
+  return launch_reduce_partials(part, launched, 2L * D, 2L * D, dgamma, 1, 1.0f, st, dbeta, D, 1);
 }
