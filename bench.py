@@ -131,14 +131,15 @@ def pmc_traffic_per_launch(B, args):
     tot = 0.0
     for name, mult in ((f'round2_pmc_FETCH_SIZE_b{B}.txt', 2.0), (f'round2_pmc_WRITE_SIZE_b{B}.txt', 1.0)):
         try:
-            got = False
+            kb, rows = 0.0, 0.0
             for line in open(os.path.join(here, 'profiles', name)):
-                if 'gemm_nt_bf16_pp_kernel' in line:
+                if 'gemm_nt_bf16_pp_kernel' in line:       # one line per template instantiation: pool them
                     f = dict(kv.split('=') for kv in line.split() if '=' in kv)
-                    tot += mult * float(f['total']) * 1024.0 / float(f['rows'])
-                    got = True
-            if not got:
+                    kb += float(f['total'])
+                    rows += float(f['rows'])
+            if rows <= 0:
                 return None
+            tot += mult * kb * 1024.0 / rows
         except (OSError, KeyError, ValueError):
             return None
     return round(tot, 0) if tot > 0 else None
