@@ -556,14 +556,23 @@ constexpr int TP_LDS_BYTES = TP_RING_BYTES + 8 * 16 * TP_STG_LD * 4;
 
 __device__ inline void tp_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+template <bool TRACE>
 __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     int M, int m_per_split, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
-    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out, long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  // phase timeline of K tiles 8..15 (tools/tn_timeline.py): shader-clock stamps of wave 0 at 13 points per K tile
+  int trace_kt = -1;
+  auto stamp = [&](int e) {
+    if constexpr (TRACE) {
+      if (tid == 0 && trace_kt >= 0)
+        trace[((long)blockIdx.x * 8 + trace_kt) * 24 + e] = (long long)__builtin_amdgcn_s_memtime();
+    }
+  };
   // XCD-aware order: the tiles of one split read the same token rows, so give every XCD a contiguous
   // run of the split-major work list (its L2 then serves each A / B row to all the tiles that need it;
   // round-robin placement re-fetches every panel once per XCD: 1.85 GB instead of 0.39 GB at 768x3072)
@@ -583,48 +592,72 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   // line per row); this wave owns pieces 2*wave, 2*wave+1.  lane -> row 8*(p%8) + lane/8, physical
   // chunk lane%8, logical chunk = physical ^ (((row>>1)&1)<<2): rows r, r+2 swap 64-B halves, which puts
   // the four rows a transpose read touches in one LDS cycle on four disjoint bank quarters.
-  int prow[2], acol[2][2], bcol[2][2];            // [piece][region half]
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int pc = wave * 2 + j, sub = pc >> 3;
-    prow[j] = (pc & 7) * 8 + (lane >> 3);
-    const int rc = sub * 64 + ((lane & 7) ^ (((prow[j] >> 1) & 1) << 2)) * 8;   // region column 0..127
-    acol[j][0] = r0 + (rc >> 6) * 128 + (rc & 63); acol[j][1] = acol[j][0] + 64;
-    bcol[j][0] = c0 + rc; bcol[j][1] = bcol[j][0] + 128;   // wave wc owns columns wc*32+[0,32) of each half
-  }
-  // Row maps without a division per DMA: phys(m) = base + m + (m / grp) * skip.  Every region kind is
-  // requested for K tiles 0, 1, 2, ... in order, so keep (quotient, remainder) of its next tile's
-  // first row in SGPRs and step them by 64 (grp > 64 or grp == 0 is checked by the host).
-  int tq[4], trm[4];
+  // The wave's two pieces are rows prow0 and prow0 + 8 of the same sub-block (2*wave is even, so 2*wave + 1 does not
+  // leave the sub-block) and (prow >> 1) & 1 is the same for both: ONE column offset per operand serves both pieces
+  // and both region halves (+64 for A1, +128 for B1).
+  const int pc0 = wave * 2, sub = pc0 >> 3;
+  const int prow0 = (pc0 & 7) * 8 + (lane >> 3);
+  const int rc = sub * 64 + ((lane & 7) ^ (((prow0 >> 1) & 1) << 2)) * 8;   // region column 0..127
+  const int acol_l = (rc >> 6) * 128 + (rc & 63);        // lane part of the A column (tile origin r0 is added as a scalar); A1: + 64
+  // B column = c0 + rc (B1: + 128): wave wc owns columns wc*32+[0,32) of each half
+  // per-lane byte offsets of piece 0 from the (scalar) address of the K tile's first row; piece 1 = 8 rows further
+  const unsigned voff_a = 2u * (unsigned)(prow0 * (int)lda + acol_l), voff_b = 2u * (unsigned)(prow0 * (int)ldb + rc);
+  // Row maps without a division per DMA: phys(m) = base + m + (m / grp) * skip.  Every region kind is requested for K
+  // tiles 0, 1, 2, ... in order, so the state of its NEXT request lives in SGPRs and is stepped by one tile after each
+  // request (`advance`, pure SALU, called from the following load section): the scalar byte address of the tile's first
+  // row (column origin included), how many of its 64 rows come before the next row-map group (`crs`, >= 64: all) and
+  // how many are inside M (`vld`).  The request itself (`issue`, which sits between the MFMAs of an MMA section) is
+  // branch-free: per piece a lane picks one of two scalar row addresses (this group / the next one) and one of two
+  // constant offsets (its own row / row 0 of the tile for rows beyond M, which are zeroed in LDS afterwards) -- about a
+  // dozen VALU instructions per region.  It used to be ~100 instructions of per-lane 64-bit address arithmetic and
+  // branches, which made every MMA section 2.3x as long as its 8 MFMAs (tools/tn_timeline.py: 600 cycles).
+  int trm[4], crs[4], vld[4];
+  const char* sp[4];
+  const long step64_a = 2L * TP_BK * lda, step64_b = 2L * TP_BK * ldb;          // bytes per K tile
+  const long skipb_a = 2L * amap.skip * lda, skipb_b = 2L * bmap.skip * ldb;    // bytes per row-map group crossing
+  constexpr int TP_FAR = 1 << 28;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int g = (k == 0 || k == 3) ? amap.grp : bmap.grp;
-    tq[k] = g > 0 ? m_begin / g : 0;
-    trm[k] = g > 0 ? m_begin - tq[k] * g : 0;
+    const bool isA = k == 0 || k == 3;
+    const vtx_rowmap& mp = isA ? amap : bmap;
+    const int g = mp.grp;
+    const int q = g > 0 ? m_begin / g : 0;
+    trm[k] = g > 0 ? m_begin - q * g : 0;
+    crs[k] = g > 0 ? g - trm[k] : TP_FAR;
+    vld[k] = M - m_begin;
+    const long phys0 = (long)mp.base + m_begin + (long)q * mp.skip;
+    sp[k] = reinterpret_cast<const char*>(isA ? A + phys0 * lda + r0 + (k == 3 ? 64 : 0) : B + phys0 * ldb + c0 + (k == 2 ? 128 : 0));
   }
-  auto issue = [&](int kind, int kt) {            // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+  auto issue_piece = [&](int kind, int kt, int j) {   // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1; piece j of this wave
     bf16raw* dst = lds + (kt & 1) * TP_BUF + kind * TP_REGION + wave * 1024;
     const bool isA = kind == 0 || kind == 3;
-    const vtx_rowmap& mp = isA ? amap : bmap;
-    const int mt = m_begin + kt * TP_BK;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int off = prow[j];
-      if (mt + off >= M) off = M - 1 - mt;        // clamp to the last valid row (zeroed in LDS afterwards)
-      const int qq = tq[kind] + ((mp.grp > 0 && trm[kind] + off >= mp.grp) ? 1 : 0);
-      const long phys = (long)mp.base + mt + off + (long)qq * mp.skip;
-      const bf16raw* src = isA ? A + phys * lda + acol[j][kind == 3] : B + phys * ldb + bcol[j][kind == 2];
-      tn_dma16(src, dst + j * 512);
+    const char* lo = sp[kind];
+    const char* hi = lo + (isA ? skipb_a : skipb_b);
+    const unsigned vo = isA ? voff_a : voff_b, vc = 2u * (unsigned)(isA ? acol_l : rc);
+    const unsigned step8 = 16u * (unsigned)(isA ? lda : ldb);
+    const int row = prow0 + 8 * j;
+    const char* base = row >= crs[kind] ? hi : lo;
+    const unsigned o = row < vld[kind] ? vo + j * step8 : vc;
+    tn_dma16(reinterpret_cast<const bf16raw*>(base + o), dst + j * 512);
+  };
+  auto issue = [&](int kind, int kt) { issue_piece(kind, kt, 0); issue_piece(kind, kt, 1); };
+  auto advance = [&](int kind) {                  // step the request state of `kind` to its next K tile
+    const bool isA = kind == 0 || kind == 3;
+    const int g = isA ? amap.grp : bmap.grp;
+    sp[kind] += isA ? step64_a : step64_b;
+    vld[kind] -= TP_BK;
+    if (g > 0) {
+      trm[kind] += TP_BK;
+      if (trm[kind] >= g) { trm[kind] -= g; sp[kind] += isA ? skipb_a : skipb_b; }
+      crs[kind] = g - trm[kind];
     }
-    trm[kind] += TP_BK;
-    if (mp.grp > 0 && trm[kind] >= mp.grp) { trm[kind] -= mp.grp; ++tq[kind]; }
   };
   auto zero_tail = [&](int kt) {                  // rows >= last_valid of tile kt (this wave's own pieces)
 #pragma unroll
     for (int kind = 0; kind < 4; ++kind)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        if (prow[j] >= last_valid)
+        if (prow0 + 8 * j >= last_valid)
           *reinterpret_cast<uint4*>(lds + (kt & 1) * TP_BUF + kind * TP_REGION + wave * 1024 + j * 512 + lane * 8) =
               make_uint4(0, 0, 0, 0);
   };
@@ -659,12 +692,16 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   int cs_next = t2;                                // next K tile whose A regions this workgroup sums
   const int cs_sub = tid >> 8, cs_row = (tid >> 3) & 31, cs_pc = tid & 7;
   float cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned cs_addr = lds_b + 2u * (cs_sub * 4096 + cs_row * 64 + cs_pc * 8);
 #define TP_COLSUM(buf_, kind_, cs_)                                                                      \
   if (do_cs) {                                                                                           \
     u32x4 v_[2];                                                                                         \
+    /* the address is rebuilt from the thread index here: kept live across the loop it is spilled, and a scratch reload \
+       waits for vmcnt(0), i.e. for the whole DMA look-ahead */                                          \
+    unsigned t_ = threadIdx.x;                                                                           \
+    asm volatile("" : "+v"(t_));                                                                         \
+    const unsigned ca_ = lds_b + 2u * ((t_ >> 8) * 4096 + ((t_ >> 3) & 31) * 64 + (t_ & 7) * 8);        \
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\ts_waitcnt lgkmcnt(0)"        \
-                 : "=&v"(v_[0]), "=&v"(v_[1]) : "v"(cs_addr + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION)) : "memory"); \
+                 : "=&v"(v_[0]), "=&v"(v_[1]) : "v"(ca_ + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION)) : "memory"); \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) _Pragma("unroll") for (int j = 0; j < 4; ++j) {     \
       cs_[2 * j] += __uint_as_float(v_[it][j] << 16);                                                    \
       cs_[2 * j + 1] += __uint_as_float(v_[it][j] & 0xffff0000u);                                        \
@@ -688,71 +725,131 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     u_.h[0] = tn_tr_read<4096>(a_); u_.h[1] = tn_tr_read<4096 + 512>(a_);  fb_[2] = u_.v;                \
     u_.h[0] = tn_tr_read<6144>(a_); u_.h[1] = tn_tr_read<6144 + 512>(a_);  fb_[3] = u_.v;                \
   }
+#define TP_READ_B_Q(buf_, kind_, fb_, Q_)                                                                \
+  {                                                                                                      \
+    const unsigned a_ = fb_addr + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION);                          \
+    union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
+    u_.h[0] = tn_tr_read<(Q_) * 2048>(a_); u_.h[1] = tn_tr_read<(Q_) * 2048 + 512>(a_); fb_[Q_] = u_.v;  \
+  }
 #define TP_PIN_A() asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),      \
                                      "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]))
 #define TP_PIN_B(fb_) asm volatile("" : "+v"(fb_[0]), "+v"(fb_[1]), "+v"(fb_[2]), "+v"(fb_[3]))
-#define TP_MMA(i0_, j_, fb_, ISSUE_)                                                                     \
+// 8 MFMAs with a hook after each of the first six: the two DMA pieces of the section's request and the four fragments
+// of a B prefetch are spread one per gap, so that no gap holds more than the ~8 issue slots one MFMA (32 cycles)
+// covers -- everything in one lump after the second MFMA left the matrix pipe idle for the length of the lump.
+#define TP_MFMA1(i_, ks_, i0_, j_, fb_)                                                                  \
+  acc[(i0_) + (i_)][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i_][ks_], fb_[ks_], acc[(i0_) + (i_)][j_], 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+#define TP_MMA(i0_, j_, fb_, H0_, H1_, H2_, H3_, H4_, H5_)                                               \
   __builtin_amdgcn_s_setprio(1);                                                                         \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
-        acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
-    if (ks == 0) { __builtin_amdgcn_sched_barrier(0); ISSUE_; __builtin_amdgcn_sched_barrier(0); }       \
-  }                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                     \
+  TP_MFMA1(0, 0, i0_, j_, fb_) H0_; __builtin_amdgcn_sched_barrier(0);                                   \
+  TP_MFMA1(1, 0, i0_, j_, fb_) H1_; __builtin_amdgcn_sched_barrier(0);                                   \
+  TP_MFMA1(0, 1, i0_, j_, fb_) H2_; __builtin_amdgcn_sched_barrier(0);                                   \
+  TP_MFMA1(1, 1, i0_, j_, fb_) H3_; __builtin_amdgcn_sched_barrier(0);                                   \
+  TP_MFMA1(0, 2, i0_, j_, fb_) H4_; __builtin_amdgcn_sched_barrier(0);                                   \
+  TP_MFMA1(1, 2, i0_, j_, fb_) H5_; __builtin_amdgcn_sched_barrier(0);                                   \
+  TP_MFMA1(0, 3, i0_, j_, fb_)                                                                           \
+  TP_MFMA1(1, 3, i0_, j_, fb_)                                                                           \
   __builtin_amdgcn_s_setprio(0);
 #define TP_BAR() __builtin_amdgcn_s_barrier()
 
   bf16x8 fa[2][4], fb0[4], fb1[4];
-  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
-  issue(0, 1); issue(1, 1); issue(2, 1);
-  // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
-  // younger request in flight (2 DMA instructions per region; the issue order is A0 B0 B1 A1 per tile).
-  tn_wait_vmcnt<10>();                            // A0(0), B0(0) landed; B1(0) A1(0) A0(1) B0(1) B1(1) in flight
+  issue(0, 0); advance(0); issue(1, 0); advance(1); issue(2, 0); advance(2); issue(3, 0); advance(3);
+  issue(0, 1); advance(0); issue(1, 1); advance(1); issue(2, 1); advance(2);
+  // Waits are per region and counted (2 DMA instructions per region; issue order per tile A0 B0 B1 A1, then in the loop
+  // A1(kt+1) in P1, A0(kt+2) in P2, B0(kt+2) in P3, B1(kt+2) in P4).  The other group runs ONE BARRIER behind, so a
+  // region is complete only two barriers after this wave's own wait: every wait sits a full phase ahead of the first
+  // read -- and the B fragments prefetched inside an MMA section are first read one barrier earlier than a load section
+  // would read them, so B1(kt+1) is waited for in P4(kt), A0 / B0(kt+1) in P3(kt), A1(kt) in P2(kt).
+  tn_wait_vmcnt<8>();                             // A0(0), B0(0), B1(0) landed; A1(0) A0(1) B0(1) B1(1) in flight
   TP_BAR();
   if (wr == 1) TP_BAR();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
-    do_cs = want_cs && kt == cs_next;
-    if (do_cs) cs_next += tiles2;
-    // (DMA requests are issued in the shadow of the MFMAs, see gemm_nt_bf16_pp_kernel)
-    // P1: reads A0, B0; P2 will read B1(kt)
-    TP_READ_A(buf, 0);
-    TP_READ_B(buf, 1, fb0);
-    TP_COLSUM(buf, 0, cs0);
-    if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<2>();
-    tp_lgkm0();
-    TP_BAR();
-    TP_PIN_A(); TP_PIN_B(fb0);
-    TP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));
-    TP_BAR();
-    // P2: reads B1; P3 will read A1(kt)
-    TP_READ_B(buf, 2, fb1);
-    if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<0>();
-    tp_lgkm0();
-    TP_BAR();
-    TP_PIN_B(fb1);
-    TP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));
-    TP_BAR();
-    // P3: reads A1
-    TP_READ_A(buf, 3);
-    TP_COLSUM(buf, 3, cs1);
-    tp_lgkm0();
-    TP_BAR();
-    TP_PIN_A();
-    TP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));
-    TP_BAR();
-    // P4: no reads; P1 of the next tile will read A0(kt+1), B0(kt+1)
-    if (n2) {
-      tn_wait_vmcnt<8>();
-    } else if (n1) {
-      if (last_valid < TP_BK) { tn_wait_vmcnt<0>(); zero_tail(kt + 1); tp_lgkm0(); } else { tn_wait_vmcnt<4>(); }
-    }
-    TP_BAR();
-    TP_MMA(2, 0, fb0, if (n2) issue(2, kt + 2));
-    TP_BAR();
+  // The load sections must not outlast the partner group's 8-MFMA section (256 cycles), and a transpose read costs
+  // ~14 cycles with four waves reading: 24 reads (A0 + B0) in P1 made every phase load-bound (tools/tn_timeline.py:
+  // 4900 cycles per K tile).  The A fragments have to be read where they are (fa is busy in every MMA section), but a
+  // B fragment set is free one phase before it is needed: B1 is read during P1's MFMAs (into Y), the NEXT tile's B0
+  // during P4's (into the registers B1 just left), so the load sections are 16 / 0 / 16 / 0 reads.  X / Y swap roles
+  // every K tile (the loop is unrolled by two).
+#define TP_KTILE(kt_, X_, Y_)                                                                            \
+  {                                                                                                      \
+    const int kt = (kt_);                                                                                \
+    const int buf = kt & 1;                                                                              \
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;                                                       \
+    do_cs = want_cs && kt == cs_next;                                                                    \
+    if (do_cs) cs_next += tiles2;                                                                        \
+    if constexpr (TRACE) trace_kt = (kt >= 8 && kt < 16) ? kt - 8 : -1;                                  \
+    stamp(0);                                                                                            \
+    /* P1: reads A0 (B0 is in X_ already); B1(kt) -- waited for in P4 of the previous tile -- is read during the MFMAs */ \
+    if (kt >= 1 && n1) advance(2);                   /* B1(kt+1) was requested in P4 of the previous tile */ \
+    TP_READ_A(buf, 0);                                                                                   \
+    TP_COLSUM(buf, 0, cs0);                                                                              \
+    tp_lgkm0();                                                                                          \
+    stamp(1);                                                                                            \
+    stamp(2);                                                                                            \
+    TP_BAR();                                                                                            \
+    stamp(3);                                                                                            \
+    TP_PIN_A(); TP_PIN_B(X_);                                                                            \
+    TP_MMA(0, 0, X_, if (n1) issue_piece(3, kt + 1, 0), if (n1) issue_piece(3, kt + 1, 1),              \
+           TP_READ_B_Q(buf, 2, Y_, 0), TP_READ_B_Q(buf, 2, Y_, 1), TP_READ_B_Q(buf, 2, Y_, 2), TP_READ_B_Q(buf, 2, Y_, 3)); \
+    stamp(15);                                                                                           \
+    TP_BAR();                                                                                            \
+    stamp(4);                                                                                            \
+    /* P2: no reads (B1 arrived in Y_ during P1); P3 will read A1(kt) */                                 \
+    if (n1) advance(3);                                                                                  \
+    tp_lgkm0();                                                                                          \
+    stamp(5);                                                                                            \
+    if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<0>();                                                 \
+    stamp(6);                                                                                            \
+    TP_BAR();                                                                                            \
+    stamp(7);                                                                                            \
+    TP_PIN_B(Y_);                                                                                        \
+    TP_MMA(0, 1, Y_, if (n2) issue_piece(0, kt + 2, 0), if (n2) issue_piece(0, kt + 2, 1), , , , );      \
+    stamp(16);                                                                                           \
+    TP_BAR();                                                                                            \
+    stamp(8);                                                                                            \
+    /* P3: reads A1 */                                                                                   \
+    if (n2) advance(0);                                                                                  \
+    TP_READ_A(buf, 3);                                                                                   \
+    TP_COLSUM(buf, 3, cs1);                                                                              \
+    if (n2) {                                                                                            \
+      tn_wait_vmcnt<6>();                            /* A0(kt+1), B0(kt+1) landed */                     \
+    } else if (n1) {                                                                                     \
+      tn_wait_vmcnt<0>();                            /* all of the last tile */                          \
+      if (last_valid < TP_BK) zero_tail(kt + 1);                                                         \
+    }                                                                                                    \
+    tp_lgkm0();                                                                                          \
+    stamp(9);                                                                                            \
+    TP_BAR();                                                                                            \
+    stamp(10);                                                                                           \
+    TP_PIN_A();                                                                                          \
+    TP_MMA(2, 1, Y_, if (n2) issue_piece(1, kt + 2, 0), if (n2) issue_piece(1, kt + 2, 1), , , , );      \
+    stamp(17);                                                                                           \
+    TP_BAR();                                                                                            \
+    stamp(11);                                                                                           \
+    /* P4: no reads of its own; B0(kt+1) (published by P3's barrier) is read into Y_ during the MFMAs */ \
+    if (n2) advance(1);                                                                                  \
+    if (n2) tn_wait_vmcnt<6>();                      /* B1(kt+1) landed */                               \
+    stamp(12);                                                                                           \
+    TP_BAR();                                                                                            \
+    stamp(13);                                                                                           \
+    TP_MMA(2, 0, X_, if (n2) issue_piece(2, kt + 2, 0), if (n2) issue_piece(2, kt + 2, 1),              \
+           if (n1) TP_READ_B_Q(buf ^ 1, 1, Y_, 0), if (n1) TP_READ_B_Q(buf ^ 1, 1, Y_, 1),               \
+           if (n1) TP_READ_B_Q(buf ^ 1, 1, Y_, 2), if (n1) TP_READ_B_Q(buf ^ 1, 1, Y_, 3));              \
+    stamp(18);                                                                                           \
+    TP_BAR();                                                                                            \
+    stamp(14);                                                                                           \
   }
+  TP_READ_B(0, 1, fb0);                            // B0 of K tile 0 (published by the barrier above); covered by P1's lgkmcnt(0)
+  for (int kt2 = 0; kt2 < nk; kt2 += 2) {
+    TP_KTILE(kt2, fb0, fb1)
+    if (kt2 + 1 < nk) TP_KTILE(kt2 + 1, fb1, fb0)
+  }
+#undef TP_KTILE
   if (wr == 0) TP_BAR();
 #undef TP_COLSUM
+#undef TP_READ_B_Q
+#undef TP_MFMA1
 #undef TP_PIN_A
 #undef TP_PIN_B
 #undef TP_READ_A
@@ -1002,12 +1099,12 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     const Options& o = options();
     const bool safe = o.tn_safe != 0, nodma = o.gemm_nodma != 0;
     const bool want_ring = o.gemm_tn != TN_DMA2 && d->M >= 1024;   // "pp256" falls back to the ring when ineligible
-    // Default: the 256x128 ring (2 workgroups per CU), except for wide-B shapes (N2 >= 4 N1: the fc2 weight gradient
-    // 768x3072), where the 256x256 ping-pong kernel's larger tile wins.  tools/tn_compare.py at M = 150528, with the fused
-    // bias-gradient sums, ring / ping-pong: 768x3072 974 / 850 us, 3072x768 791 / 858, 2304x768 603 / 672, 768x768 219 / 240.
-    // gemm_tn=pp256 / ring force one of them.
+    // Default: the 256x256 ping-pong kernel wherever it is eligible (M >= 4096, N1 and N2 multiples of 256, row-map
+    // groups > 64 rows), the 256x128 ring (2 workgroups per CU) otherwise.  tools/tn_compare.py at M = 150528 with the
+    // fused bias-gradient sums, ring / ping-pong: 768x3072 974 / 731 us, 3072x768 791 / 708, 2304x768 603 / 551,
+    // 768x768 219 / 208.  gemm_tn=pp256 / ring force one of them.
     const bool pp_fits = tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
-    const bool want_pp = pp_fits && (o.gemm_tn == TN_PP256 || (o.gemm_tn == TN_AUTO && d->N2 >= 4 * d->N1));
+    const bool want_pp = pp_fits && (o.gemm_tn == TN_PP256 || o.gemm_tn == TN_AUTO);
     if (!safe && !nodma && want_pp) {
       const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
       const int s_p = tp_splits(d->M, d->N1, d->N2);
@@ -1015,13 +1112,19 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
       const int s_eff = s_p;
       static bool attr_set_p = false;
       if (!attr_set_p) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES);
         attr_set_p = true;
       }
       if (m_per_p >= 2 * TP_BK) {
         out.slab_stride = w_elems + (long)t2p * d->N1; out.cs_fold = t2p;
-        hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel, dim3(t1p * t2p * s_eff), dim3(TP_THREADS), TP_LDS_BYTES, st, d->M, m_per_p,
-                           (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out);
+        long long* trace_p = reinterpret_cast<long long*>(o.pp_trace);
+        if (trace_p)                                 // diagnostic instantiation with the phase stamps (tools/tn_timeline.py)
+          hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<true>, dim3(t1p * t2p * s_eff), dim3(TP_THREADS), TP_LDS_BYTES, st, d->M, m_per_p,
+                             (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out, trace_p);
+        else
+          hipLaunchKernelGGL(gemm_tn_bf16_pp_kernel<false>, dim3(t1p * t2p * s_eff), dim3(TP_THREADS), TP_LDS_BYTES, st, d->M, m_per_p,
+                             (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out, nullptr);
         int rc_p = check_launch("gemm_tn_pp");
         if (rc_p) return rc_p;
         if (!d->colsum) return launch_reduce_partials(out.slab, s_eff, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
