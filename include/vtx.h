@@ -59,8 +59,11 @@ const char* vtx_last_error_string(void);
  * read once): "gemm_nt" = auto|pp256|dma2|ring128x3|ring128x4k32|ring256x3|ring256x3k32|ring256x4k32,
  * "gemm_tn" = auto|pp256|ring|dma2, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "pp_grid", "pp_cg",
  * "pp_epi" = integers ("pp_epi": 1 = per-pass epilogue of the persistent GEMM; 2 / 3 = timing diagnostics that skip
- * its stores / its LDS staging and produce WRONG output), "pp_trace" = device address of a timeline buffer
- * (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown name or value. */
+ * its stores / its LDS staging and produce WRONG output), "pp_cont" = 0|1 (continuous flow of the persistent GEMM: the
+ * next tile's first K tiles are requested inside the current main loop; 1 by default, 0 = per-tile prologue; identical
+ * results), "pp_touch" = k (k > 0: cache warm-up reads of the residual / multiplier block at K tile k; identical
+ * results), "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown
+ * name or value. */
 int vtx_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------ LayerNorm
@@ -84,8 +87,8 @@ int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, vtx
  * (:225,267), FFN (:498-507,520-521), the patch/tubelet projection after the
  * patch gather (:116-126,142,146), MaskFeat decoder_pred
  * (video_transformer.py:855,878).
- * Epilogue order:  v = acc (+bias[n]);  act GELU(erf): C2 = v, v = gelu(v);
- *                  v *= gelu'(dgelu_in[m][n]);  v *= row_scale[idx(m)];
+ * Epilogue order:  v = acc (+bias[n]);  act 1 (erf GELU): C2 = v, v = gelu(v);  act 2: C2 = gelu'(v), v = gelu(v);
+ *                  v *= gelu'(dgelu_in[m][n])  (dgelu_kind 1: v *= dgelu_in[m][n]);  v *= row_scale[idx(m)];
  *                  v += R[rmap(m) or m % r_period][n];  C[cmap(m)][n] = v.
  * Rows m >= split_row (if split_row > 0) are stored to Csplit[m - split_row]
  * with bias/act/scale applied but no residual (the per-frame cls rows of the
@@ -97,9 +100,11 @@ typedef struct {
   const void* B; long ldb;            /* [N,K], K contiguous */
   void* C; long ldc; vtx_rowmap cmap;
   const float* bias;                  /* [N] or NULL */
-  int act;                            /* 0 none, 1 GELU(erf) */
-  void* C2; long ldc2;                /* pre-activation copy when act == 1 (may be NULL) */
+  int act;                            /* 0 none, 1 GELU(erf), 2 GELU(erf) with the derivative as second output */
+  void* C2; long ldc2;                /* act 1: pre-activation copy (may be NULL); act 2: gelu'(pre-activation), required
+                                         -- what the FFN backward multiplies by, so that its epilogue needs no erf / exp */
   const void* dgelu_in; long ld_dgelu;/* multiply by gelu'(x) (FFN backward), or NULL */
+  int dgelu_kind;                     /* 0: dgelu_in holds x (the act-1 copy); 1: it holds gelu'(x) itself (the act-2 output) */
   const float* row_scale;             /* DropPath keep-scale per row group, or NULL */
   int rs_d1, rs_m1, rs_d2, rs_m2;     /* idx(m) = (m / rs_d1) * rs_m1 + (m % rs_d2) * rs_m2 */
   const void* R; long ldr; vtx_rowmap rmap; int r_period; /* residual; r_period>0: row m % r_period */

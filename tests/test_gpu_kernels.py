@@ -143,6 +143,14 @@ def test_gemm_nt_epilogues(dtype):
     ref = (Aq @ Wq.t()) * hq.grad
     ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, dgelu_in=dev(h, dtype))
     check(f'gemm dgelu {dtype}', C.float().cpu(), ref, TOL[dtype])
+    # (2b) act 2: GELU with its derivative as second output; dgelu_kind 1: multiply by that output as stored
+    preq = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(preq).sum().backward()
+    ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, bias=dev(bias), act=2, C2=C2)
+    check(f'gemm gelu (act 2) {dtype}', C.float().cpu(), torch.nn.functional.gelu(pre), TOL[dtype])
+    check(f"gemm gelu' out {dtype}", C2.float().cpu(), preq.grad, TOL[dtype])
+    ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, dgelu_in=dev(h, dtype), dgelu_kind=1)
+    check(f'gemm mul {dtype}', C.float().cpu(), (Aq @ Wq.t()) * q(h, dtype), TOL[dtype])
     # (3) A rows through the token map, per-(b,p) row scale, residual + output through the map
     X = rnd(B, 1 + N, D, seed=5)
     R = rnd(B, 1 + N, Hd, seed=6)
@@ -211,6 +219,16 @@ def test_gemm_nt_pp_epilogues(Hd, epi, vtx_opts):
         C.fill_(float('nan'))
         ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, dgelu_in=dev(h, dtype))
         check(f'{tag} dgelu', C.float().cpu(), (Aq @ Wq.t()) * hq.grad, 1e-2)
+        # (2b) act 2 (derivative as second output) and dgelu_kind 1 (multiply by it as stored)
+        preq = pre.clone().requires_grad_(True)
+        torch.nn.functional.gelu(preq).sum().backward()
+        C.fill_(float('nan')); C2.fill_(float('nan'))
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, bias=dev(bias), act=2, C2=C2)
+        check(f'{tag} gelu (act 2)', C.float().cpu(), torch.nn.functional.gelu(pre), 1e-2)
+        check(f"{tag} gelu' out", C2.float().cpu(), preq.grad, 1e-2)
+        C.fill_(float('nan'))
+        ops.gemm_nt(dev(A, dtype), dev(W, dtype), C, M, Hd, D, dgelu_in=dev(h, dtype), dgelu_kind=1)
+        check(f'{tag} mul', C.float().cpu(), (Aq @ Wq.t()) * q(h, dtype), 1e-2)
         # (3) A rows through the token map, per-(b,p) row scale, residual + output through the map
         X, R = rnd(B, 1 + N, D, seed=5), rnd(B, 1 + N, Hd, seed=6)
         s = (torch.rand(M // T, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7
@@ -277,6 +295,84 @@ def test_gemm_nt_pp_epilogue_structures_agree(vtx_opts):
             ops.gemm_nt(A, W, C_side, M, N, K, bias=b, row_scale=s, R=R)
     torch.cuda.synchronize()
     assert torch.equal(C_main, outs[0]) and torch.equal(C_side, outs[0])
+
+
+@pytest.mark.parametrize('K', [128, 192, 768])
+@pytest.mark.parametrize('N', [256, 320, 768])
+def test_gemm_nt_pp_continuous_flow(N, K, vtx_opts):
+    """Continuous flow of the persistent kernel (pp_cont=1: the next tile's first K tiles are requested inside the
+    current main loop, tile indices and bias travel through LDS) against the per-tile-prologue flow (pp_cont=0):
+    bit-identical outputs, for an even and an odd number of K tiles (ring parity), 2 K tiles (the minimum), ragged row
+    and column tiles, one and many tiles per workgroup, identity and cls-skipping row maps on A, with and without bias /
+    GELU; and both against the float64 reference."""
+    from vtx import ops
+    dtype = torch.bfloat16
+    vtx_opts('gemm_nt', 'pp256')
+    B, P, T = 3, 196, 4
+    Ntok = P * T
+    M = B * Ntok                                   # 2352 rows: 10 row tiles, the last one ragged
+    tm = ops.tokmap(Ntok)
+    X = rnd(B, 1 + Ntok, K, seed=1)
+    W, bias = rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
+    Xd, Wd, bd = dev(X, dtype), dev(W, dtype), dev(bias)
+    Xq, Wq = q(X, dtype), q(W, dtype)
+    cases = {
+        'plain': (dict(), Xq.reshape(-1, K)[:M] @ Wq.t()),
+        'bias+map': (dict(amap=tm, bias=bd), Xq[:, 1:].reshape(M, K) @ Wq.t() + bias.double()),
+    }
+    pre = Xq[:, 1:].reshape(M, K) @ Wq.t() + bias.double()
+    preq = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(preq).sum().backward()
+    for grid in ('256', '8'):
+        vtx_opts('pp_grid', grid)
+        for name, (kw, ref) in cases.items():
+            outs = []
+            for cont in ('1', '0'):
+                vtx_opts('pp_cont', cont)
+                C = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
+                ops.gemm_nt(Xd, Wd, C, M, N, K, **kw)
+                outs.append(C)
+            check(f'cont {name} N={N} K={K} grid={grid}', outs[0].float().cpu(), ref, 1e-2)
+            assert torch.equal(outs[0], outs[1]), f'{name} N={N} K={K} grid={grid}: continuous flow changes the result'
+        outs = []
+        for cont in ('1', '0'):
+            vtx_opts('pp_cont', cont)
+            C = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
+            C2 = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
+            ops.gemm_nt(Xd, Wd, C, M, N, K, amap=tm, bias=bd, act=2, C2=C2)
+            outs.append((C, C2))
+        check(f'cont gelu N={N} K={K} grid={grid}', outs[0][0].float().cpu(), torch.nn.functional.gelu(pre), 1e-2)
+        check(f"cont gelu' N={N} K={K} grid={grid}", outs[0][1].float().cpu(), preq.grad, 1e-2)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # repeated launches on one stream (self-resetting counters, LDS hand-over words) stay identical
+    vtx_opts('pp_cont', '1')
+    vtx_opts('pp_grid', '256')
+    first = None
+    for _ in range(5):
+        C = torch.empty(M, N, dtype=dtype, device=DEV)
+        ops.gemm_nt(Xd, Wd, C, M, N, K, amap=tm, bias=bd)
+        first = C if first is None else first
+        assert torch.equal(C, first)
+
+
+def test_gemm_nt_pp_touch_option(vtx_opts):
+    """pp_touch only warms the cache for the residual / multiplier block: results are unchanged."""
+    from vtx import ops
+    dtype = torch.bfloat16
+    vtx_opts('gemm_nt', 'pp256')
+    M, N, K = 5000, 768, 256
+    A, W, b = dev(rnd(M, K, seed=1), dtype), dev(rnd(N, K, seed=2) * K ** -0.5, dtype), dev(rnd(N, seed=3))
+    R = dev(rnd(M, N, seed=4), dtype)
+    outs = []
+    for touch in ('0', '1', '3'):
+        vtx_opts('pp_touch', touch)
+        C = torch.empty(M, N, dtype=dtype, device=DEV)
+        ops.gemm_nt(A, W, C, M, N, K, bias=b, R=R)
+        D = torch.empty(M, N, dtype=dtype, device=DEV)
+        ops.gemm_nt(A, W, D, M, N, K, dgelu_in=R, dgelu_kind=1)
+        outs.append((C, D))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -1,7 +1,7 @@
 """Per-shape table of the 14 vtx_gemm_nt and 7 vtx_gemm_tn launches of one TimeSformer-B layer
 (fwd + dgrad + wgrad) with the epilogue each one really runs (GPU box only).
 
-    python tools/gemm_shapes.py [clips] [frames] [--stream-f32]
+    python tools/gemm_shapes.py [clips] [frames] [--stream-f32] [--old-gelu]
 
 Per launch: time (HIP events, 20 launches), TFLOP/s, ALGORITHMIC bytes (every operand the launch
 must read or write once: A, the weight, C, and the epilogue's residual / pre-activation copy /
@@ -77,7 +77,9 @@ def main():
     nt('qkv_s fwd', Ms, 3 * D, D, Ms * 3 * D * es, bias=bias[3 * D])
     nt('proj_s fwd (+x)', Mo, D, D, 2 * Mt * D * ss + B * T * D * ss, C=out, cmap=tm, bias=bias[D], row_scale=sv_s,
        rs=(N, T, T, 1), R=x, rmap=tm, split_row=B * N, Csplit=a_cls)
-    nt('fc1 fwd (h,g)', Ms, Hd, D, 2 * Ms * Hd * es, C=g, bias=bias[Hd], act=1, C2=h)
+    nt("fc1 fwd (g,g')", Ms, Hd, D, 2 * Ms * Hd * es, C=g, bias=bias[Hd], act=2, C2=h)
+    if '--old-gelu' in sys.argv:
+        nt('fc1 fwd (h,g) old', Ms, Hd, D, 2 * Ms * Hd * es, C=g, bias=bias[Hd], act=1, C2=h)
     nt('fc2 fwd (+x)', Ms, D, Hd, 2 * Ms * D * ss, C=out.view(Ms, D), bias=bias[D], row_scale=sv_f, rs=(N + 1, 1, 1, 0),
        R=x.view(Ms, D))
     # ---- input gradients
@@ -87,7 +89,9 @@ def main():
     nt('qkv_t dgrad', Mt, D, 3 * D, Mt * D * es)
     nt('proj_s dgrad', Mo, D, D, Mo * D * es)
     nt('qkv_s dgrad', Ms, D, 3 * D, Ms * D * es)
-    nt('fc2 dgrad (gelu\')', Ms, Hd, D, 2 * Ms * Hd * es, dgelu_in=h)
+    nt("fc2 dgrad (*g')", Ms, Hd, D, 2 * Ms * Hd * es, dgelu_in=h, dgelu_kind=1)
+    if '--old-gelu' in sys.argv:
+        nt("fc2 dgrad (gelu') old", Ms, Hd, D, 2 * Ms * Hd * es, dgelu_in=h)
     nt('fc1 dgrad', Ms, D, Hd, Ms * D * es)
 
     def tn(tag, M, N1, N2, **kw):

@@ -128,6 +128,16 @@ __device__ inline float gelu_erf_grad(float x) {
   const float xs = x * 0.3989422804014327f;
   return fmaf(xs, g, cdf);
 }
+// value and derivative from ONE evaluation of the shared parts (the FFN forward writes both: the backward's
+// epilogue is then a plain multiply); each equals gelu_erf / gelu_erf_grad of the same x bit for bit
+__device__ inline void gelu_erf_both(float x, float& val, float& grad) {
+#pragma clang fp contract(off)
+  float cdf, g;
+  gelu_parts(x, cdf, g);
+  const float xs = x * 0.3989422804014327f;
+  grad = fmaf(xs, g, cdf);
+  val = x * cdf;
+}
 
 // ---- tuning / diagnostic switches ----------------------------------------------------
 // Process-wide, set through vtx_set_option() (initial values come from the VTX_* environment
@@ -143,6 +153,9 @@ struct Options {
   int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
   int pp_cg = 0;             // VTX_GEMM_PP_CG: column tiles per group (0: from K)
   int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing); 2 / 3 = diagnostics: no stores / no staging
+  int pp_cont = 1;           // VTX_GEMM_PP_CONT: continuous flow of the persistent NT GEMM (next tile's first K tiles requested
+                             // inside the current main loop) for epilogues that leave the operand ring alone; 0 = per-tile prologue
+  int pp_touch = 0;          // VTX_GEMM_PP_TOUCH: k > 0 = touch the residual / multiplier block's lines at K tile k (cache warm-up)
   unsigned long long pp_trace = 0;   // device address of a long long[256][8][8] timeline buffer (tools/pp_timeline.py), 0 = off
 };
 Options& options();

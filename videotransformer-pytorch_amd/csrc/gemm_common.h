@@ -14,7 +14,7 @@ struct EpiParams {
   void* C; long ldc; vtx_rowmap cmap;
   const float* bias;
   int act; void* C2; long ldc2;
-  const void* dgelu_in; long ld_dgelu;
+  const void* dgelu_in; long ld_dgelu; int dgelu_kind;
   const float* row_scale; int rs_d1, rs_m1, rs_d2, rs_m2;
   const void* R; long ldr; vtx_rowmap rmap; int r_period;
   int split_row; void* Csplit; long ldsplit;
@@ -131,15 +131,30 @@ __device__ inline void epilogue(const EpiParams& p, const float* stage, int m_ba
       for (int u = 0; u < UB; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[u][j] = gelu_erf(v[u][j]);
+    } else if (p.act == 2) {                     // GELU with its derivative as the second output
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        float gp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gelu_erf_both(v[u][j], v[u][j], gp[j]);
+        if (ok[u]) store8(reinterpret_cast<T*>(p.C2) + (long)m[u] * p.ldc2 + n, gp);
+      }
     }
     if (p.dgelu_in) {
       float h[UB][8];
 #pragma unroll
       for (int u = 0; u < UB; ++u) load8(reinterpret_cast<const T*>(p.dgelu_in) + (long)ml[u] * p.ld_dgelu + n, h[u]);
+      if (p.dgelu_kind == 1) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u)
+        for (int u = 0; u < UB; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[u][j] *= gelu_erf_grad(h[u][j]);
+          for (int j = 0; j < 8; ++j) v[u][j] *= h[u][j];
+      } else {
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] *= gelu_erf_grad(h[u][j]);
+      }
     }
     if (p.row_scale) {
       float sc[UB];

@@ -370,11 +370,13 @@ __device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory
 // epilogue stages through its own 32 KB of LDS, and its stores drain under the next main loop.
 // (vmcnt counts loads and stores together; a counted wait can therefore over-wait on stores but never
 // under-wait on the DMA, because loads retire in order among themselves.)
-template <bool EPI2, bool HAS_PRE, bool HAS_SC>
+// PRE: what the epilogue reads per element: 0 nothing, 1 the residual, 2 the GELU' input x, 3 a plain multiplier
+enum { PRE_NONE = 0, PRE_RES = 1, PRE_DGELU = 2, PRE_MUL = 3 };
+template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int CG, int* __restrict__ tile_ctr,
-    long long* __restrict__ trace, int dbg, EpiParams ep) {
+    long long* __restrict__ trace, int dbg, int touch, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -441,37 +443,64 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     if (tid == 0) v = atomicAdd(my_ctr, 1);
     return publish(v);
   };
-  const bf16raw* src[4][2];                      // region kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
-  int m0 = 0, n0 = 0;
-  auto set_tile = [&](int t) {                  // t = local tile index of this XCD
+  static_assert(!CONT || (EPI2 && PRE == PRE_NONE && !HAS_SC), "the continuous flow needs an idle operand ring in the epilogue");
+  // Request addresses = a wave-uniform 64-bit base per operand (first byte of the tile's A rows / B rows, in scalar
+  // registers, advanced by scalar adds) + a 32-bit byte offset per lane and piece: the DMA instruction takes both
+  // (saddr + voffset), so a request costs no vector ALU work inside the MFMA sections and the eight per-lane
+  // pointers take 8 registers instead of 16.  (vtx_gemm_nt checks that a tile's rows span < 2 GB.)
+  const char* abase = nullptr;
+  const char* bbase = nullptr;
+  unsigned off[4][2];                            // region kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+  int m0 = 0, n0 = 0;                            // origin of the tile being computed
+  int m0s = 0, n0s = 0;                          // origin of the tile set_tile() was last called for
+  int par = 0;                                   // CONT: ring buffer of the current tile's K tile 0
+  auto set_tile = [&](int t, long koff) {       // t = local tile index of this XCD; bases are biased by -koff bytes
     const int grp_tiles = nrow * CG;             // tiles in a full column group
     const int g = t / grp_tiles;
     const int wg = min(CG, tiles_n - g * CG);    // width of this group (the last one may be narrower)
     const int r = t - g * grp_tiles;
     const int rr = r / wg, cc = r - rr * wg;
     const int tm = rlo + rr, tn = g * CG + cc;
-    m0 = tm * PP_BM; n0 = tn * PP_BN;
-    const TileMap am = make_tile_map(amap, m0);
+    m0s = tm * PP_BM; n0s = tn * PP_BN;
+    const TileMap am = make_tile_map(amap, m0s);
     const int m_last = M - 1;
-    const long a_last = map_row(amap, m_last);   // clamp target of rows beyond M (ragged last tile only)
+    const long first = tile_map_row(am, amap, m0s);          // physical row of the tile's first row
+    abase = reinterpret_cast<const char*>(A + first * lda) - koff;
+    bbase = reinterpret_cast<const char*>(B + (long)n0s * ldb) - koff;
+    // Row offsets relative to the tile's first physical row, in 32-bit arithmetic (the launcher guarantees that a
+    // tile's rows span < 2 GB).  Row maps with grp >= 256 (or none) cross a group boundary at most once inside a
+    // tile: local row l sits at l + (l >= bl ? skip : 0).  The continuous kernels are only launched for those.
+    const int ml = min(m_last - m0s, PP_BM - 1);              // last valid local row (ragged last row tile)
+    const int bl = am.fast ? am.bound - m0s : 0x7fffffff;    // local row at which the skip starts
+    const unsigned lda2 = (unsigned)lda * 2u, ldb2 = (unsigned)ldb * 2u;
+    const int nl = min(N - 1 - n0s, PP_BN - 1);               // last valid local column (ragged last column tile)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                // this wave owns pieces 2*wave, 2*wave+1 (8 region rows each)
       const int rho = (wave * 2 + j) * 8 + (lane >> 3);
-      const int c = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;
-      const int ma0 = m0 + (rho >> 6) * 128 + (rho & 63), ma1 = ma0 + 64;
-      int nb0 = n0 + (rho >> 5) * 64 + (rho & 31), nb1 = nb0 + 32;
-      if (nb0 >= N) nb0 = N - 1;
-      if (nb1 >= N) nb1 = N - 1;
-      src[0][j] = A + (ma0 > m_last ? a_last : tile_map_row(am, amap, ma0)) * lda + c;
-      src[3][j] = A + (ma1 > m_last ? a_last : tile_map_row(am, amap, ma1)) * lda + c;
-      src[1][j] = B + (long)nb0 * ldb + c;
-      src[2][j] = B + (long)nb1 * ldb + c;
+      const unsigned c2 = (unsigned)(((lane & 7) ^ ((rho >> 1) & 7)) * 16);
+      const int la0 = min((rho >> 6) * 128 + (rho & 63), ml), la1 = min((rho >> 6) * 128 + (rho & 63) + 64, ml);
+      const int lb0 = min((rho >> 5) * 64 + (rho & 31), nl), lb1 = min((rho >> 5) * 64 + (rho & 31) + 32, nl);
+      unsigned ra0, ra1;
+      if (CONT || am.fast) {
+        ra0 = (unsigned)(la0 + (la0 >= bl ? am.skip : 0));
+        ra1 = (unsigned)(la1 + (la1 >= bl ? am.skip : 0));
+      } else {
+        ra0 = (unsigned)(map_row(amap, m0s + la0) - first);
+        ra1 = (unsigned)(map_row(amap, m0s + la1) - first);
+      }
+      off[0][j] = ra0 * lda2 + c2;
+      off[3][j] = ra1 * lda2 + c2;
+      off[1][j] = (unsigned)lb0 * ldb2 + c2;
+      off[2][j] = (unsigned)lb1 * ldb2 + c2;
     }
   };
-  auto issue = [&](int kind, int kt) {           // region `kind` of K tile kt -> buffer kt&1
-    bf16raw* dst = lds + (kt & 1) * PP_BUF + kind * PP_REGION + wave * 1024;
-    dma16(src[kind][0] + kt * PP_BK, dst);
-    dma16(src[kind][1] + kt * PP_BK, dst + 512);
+  auto issue = [&](int kind, int kt) {           // region `kind` of K tile kt -> buffer (kt&1)^par
+    bf16raw* dst = lds + ((kt & 1) ^ par) * PP_BUF + kind * PP_REGION + wave * 1024;
+    const char* base = ((kind == 0 || kind == 3) ? abase : bbase) + (long)kt * (PP_BK * 2);
+    asm volatile("" : "+s"(base));               // keep it a scalar base (saddr form): hipcc would otherwise strength-reduce
+                                                 // base + offset into 64-bit per-lane pointers again
+    dma16(reinterpret_cast<const bf16raw*>(base + off[kind][0]), dst);
+    dma16(reinterpret_cast<const bf16raw*>(base + off[kind][1]), dst + 512);
   };
   auto prologue = [&]() {                        // tile 0 complete + 3 regions of tile 1 (nk >= 2)
     issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
@@ -503,12 +532,69 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   __builtin_amdgcn_s_setprio(0);
 #define PP_BAR() __builtin_amdgcn_s_barrier()
 
+  // One 64-deep K tile = four phases.  N1_ / N2_: "K tile kt+1 / kt+2 exists" (in this tile, or -- continuous flow --
+  // as K tile 0 / 1 of the next tile); H1_ .. H4_: hooks inside the load sections of P1 .. P4.
+  // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section): inside a load
+  // section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
+#define PP_KTILE(N1_, N2_, H1_, H2_, H3_, H4_)                                                              \
+    {                                                                                                  \
+      const int buf = (kt & 1) ^ par;                                                                  \
+      const bool n1 = (N1_), n2 = (N2_);                                                               \
+      /* P1: reads A0, B0; P2 will read B1(kt) */                                                      \
+      PP_READ_A(buf, 0);                                                                               \
+      PP_READ_B(buf, 1, fb0);                                                                          \
+      if (n1) wait_vmcnt<8>(); else wait_vmcnt<2>();                                                   \
+      H1_                                                                                              \
+      lgkm0();                                                                                         \
+      PP_BAR();                                                                                        \
+      PP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));                                                     \
+      PP_BAR();                                                                                        \
+      /* P2: reads B1; P3 will read A1(kt) */                                                          \
+      PP_READ_B(buf, 2, fb1);                                                                          \
+      if (n1) wait_vmcnt<8>(); else wait_vmcnt<0>();                                                   \
+      H2_                                                                                              \
+      lgkm0();                                                                                         \
+      PP_BAR();                                                                                        \
+      PP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));                                                     \
+      PP_BAR();                                                                                        \
+      /* P3: reads A1 */                                                                               \
+      PP_READ_A(buf, 3);                                                                               \
+      H3_                                                                                              \
+      lgkm0();                                                                                         \
+      PP_BAR();                                                                                        \
+      PP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));                                                     \
+      PP_BAR();                                                                                        \
+      /* P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1) */                           \
+      if (n2) wait_vmcnt<8>(); else if (n1) wait_vmcnt<4>();                                           \
+      H4_                                                                                              \
+      PP_BAR();                                                                                        \
+      PP_MMA(2, 0, fb0, if (n2) issue(2, kt + 2));                                                     \
+      PP_BAR();                                                                                        \
+    }
+
+  // Continuous flow (CONT: epilogues that leave the operand ring alone).  The K tiles of successive tiles form ONE
+  // stream through the ring: the requests that the last two K tiles of a tile have no use for -- exactly the seven
+  // regions of the old per-tile prologue -- fetch K tiles 0 and 1 of the NEXT tile under the same WAR / RAW rules as
+  // any other K tile, so a tile starts with its operands on chip and nothing is requested between two main loops.
+  // That needs the next tile's index two K tiles before the end of the current one:
+  //   t      tile being computed            t_next  tile after it (known when the tile starts)
+  //   t_nn   tile after t_next: drawn by lane 0 at K tile 0 (one atomic), handed to the other waves through an LDS
+  //          word at K tile 1 -- both inside the main loop, under its counted waits, at no barrier of their own.
+  // Nothing may wait for "all outstanding requests" any more (there always are next-tile requests in flight), so
+  // the bias reaches the epilogue through LDS as well: one 256-B LDS-DMA per wave at K tile 0 into its idle
+  // staging slice, read back into two registers before the first pass.
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned slot_rd = (unsigned)(unsigned long)(lds_char*)(smem + PP_RING_BYTES);
+  const unsigned bias_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 256 + (lane & 31) * 4);
   int t = next_tile();
   const int tend = xcount;
   if (t >= tend) { check_out(); return; }
-  int pending = 0;                               // EPI2: index drawn for the tile after `t` (lane 0 of the workgroup)
-  if (EPI2 && tid == 0) pending = atomicAdd(my_ctr, 1);
-  set_tile(t);
+  int t_next = tend, t_nn = tend;
+  if constexpr (CONT) t_next = next_tile();
+  int pending = 0;                               // index drawn ahead by lane 0 of the workgroup
+  if (EPI2 && !CONT && tid == 0) pending = atomicAdd(my_ctr, 1);
+  set_tile(t, 0);
+  m0 = m0s; n0 = n0s;
   prologue();
   while (true) {
     f32x16 acc[4][2];
@@ -519,6 +605,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 fa[2][4], fb0[4], fb1[4];
+    const bool more_c = CONT && t_next < tend;   // continuous flow: another tile follows this one
     // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
     // younger request in flight (2 DMA instructions per region; issue order A0 B0 B1 A1 per K tile).
     stamp(0);
@@ -526,37 +613,77 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     PP_BAR();
     stamp(1);
     if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
-      // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section):
-      // inside a load section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
-      // P1: reads A0, B0; P2 will read B1(kt)
-      PP_READ_A(buf, 0);
-      PP_READ_B(buf, 1, fb0);
-      if (n1) wait_vmcnt<8>(); else wait_vmcnt<2>();
-      lgkm0();
-      PP_BAR();
-      PP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));
-      PP_BAR();
-      // P2: reads B1; P3 will read A1(kt)
-      PP_READ_B(buf, 2, fb1);
-      if (n1) wait_vmcnt<8>(); else wait_vmcnt<0>();
-      lgkm0();
-      PP_BAR();
-      PP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));
-      PP_BAR();
-      // P3: reads A1
-      PP_READ_A(buf, 3);
-      lgkm0();
-      PP_BAR();
-      PP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));
-      PP_BAR();
-      // P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1)
-      if (n2) wait_vmcnt<8>(); else if (n1) wait_vmcnt<4>();
-      PP_BAR();
-      PP_MMA(2, 0, fb0, if (n2) issue(2, kt + 2));
-      PP_BAR();
+    if constexpr (CONT) {
+      // bias of this wave's 64 columns -> staging slice (+256 B): lane l fetches column en0 + l
+      auto bias_dma = [&]() {
+        if (ep.bias) {
+          const int c = n0 + wc * 64 + lane;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ep.bias + (c < ep.N ? c : 0)),
+                                           (__attribute__((address_space(3))) void*)(stg + 64), 4, 0, 0);
+        }
+      };
+      // The draw.  hipcc cannot be allowed to see it: (a) its atomic optimizer aggregates a uniform-address atomic over
+      // the wave and reads the result back at once; (b) its wait-count pass treats every LDS-DMA as a FLAT access that
+      // may return out of order, so ANY vector-memory result it tracks is waited for with vmcnt(0) while a DMA is in
+      // flight -- and here one always is.  So: the atomic and the LDS store of its result are inline asm, both inside
+      // K tile 0 of the main loop (straight-line code between them), and the store sits behind an explicit counted
+      // wait: lane 0's wave issues the bias DMA (0 or 1) + six operand requests between the two, so vmcnt(6) means the
+      // atomic has returned.  `drawn` must not be touched by anything else (checked in the ISA: one def, one use).
+      int drawn = 0;
+      const int one = 1;
+      int kt = 0;
+      if (more_c) {
+        // every request of every K tile is unconditional here
+        for (; kt < nk; ++kt) {
+          PP_KTILE(true, true,
+                   if (kt == 0) {
+                     if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(my_ctr), "v"(one) : "memory");
+                     bias_dma();
+                   },
+                   if (kt == nk - 2) set_tile(t_next, (long)nk * (PP_BK * 2));,      /* after P1's A1(nk-1): the last in-tile request */
+                   if (kt == 1) {
+                     int v;
+                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(slot_rd) : "memory");
+                     t_nn = __builtin_amdgcn_readfirstlane(v);
+                   },
+                   if (kt == 0 && wave == 0) {
+                     wait_vmcnt<6>();
+                     if (tid == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(slot_rd), "v"(drawn) : "memory");
+                     lgkm0();
+                   })
+        }
+      } else {
+        for (; kt < nk; ++kt) {
+          PP_KTILE(kt + 1 < nk, kt + 2 < nk, if (kt == 0) bias_dma();, , , )
+        }
+      }
+    } else {
+      // Option pp_touch = k > 0: at K tile k every lane reads one word of two rows of the wave's residual / multiplier
+      // block (a row of the block is one 128-B line) into the idle staging slice, so that the block's lines are on
+      // their way into the cache hierarchy long before the epilogue requests all 128 KB of them at once.
+      auto touch_pre = [&]() {
+        if constexpr (EPI2 && PRE != PRE_NONE) {
+          const bool res = PRE == PRE_RES;
+          const bf16raw* const base = reinterpret_cast<const bf16raw*>(res ? ep.R : ep.dgelu_in);
+          const long ld = res ? ep.ldr : ep.ld_dgelu;
+          const int c = n0 + wc * 64 < ep.N ? n0 + wc * 64 : 0;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int ml = m0 + wr * 128 + h * 64 + lane;
+            if (ml > ep.M - 1) ml = ep.M - 1;
+            long rr = ml;
+            if (res) {
+              const bool split = ep.split_row > 0 && ml >= ep.split_row;
+              rr = split ? 0 : (ep.r_period > 0 ? (long)(ml % ep.r_period) : map_row(ep.rmap, ml));
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + rr * ld + c),
+                                             (__attribute__((address_space(3))) void*)(stg + 128 + h * 64), 4, 0, 0);
+          }
+        }
+      };
+      for (int kt = 0; kt < nk; ++kt) {
+        PP_KTILE(kt + 1 < nk, kt + 2 < nk, if (touch > 0 && kt == touch) touch_pre();, , , )
+      }
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
     stamp(2);
@@ -564,7 +691,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     if constexpr (!EPI2) {
       t = next_tile();
       const bool more = t < tend;
-      if (more) { set_tile(t); prologue(); }        // ring is free: request the next tile before the epilogue
+      if (more) { set_tile(t, 0); m0 = m0s; n0 = n0s; prologue(); }   // ring is free: request the next tile before the epilogue
       // eight 16-row passes, expanded by hand: a loop here makes the compiler index acc[] dynamically
       // (= the whole accumulator goes through scratch)
 #define PP_EPI(mi_, half_)                                                                              \
@@ -585,9 +712,12 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // The index of the next tile was drawn one tile ago (`pending`): publishing it costs two barriers,
       // not an atomic round trip; the draw for the tile after it goes out below and returns under the
       // epilogue's own load latency.
-      t = publish(pending);
+      bool more = more_c;
+      if constexpr (!CONT) {
+        t = publish(pending);
+        more = t < tend;
+      }
       stamp(3);
-      const bool more = t < tend;
       // Every global READ of the epilogue happens HERE, before the tile's first store.  vmcnt counts loads and
       // stores together and a wait can only name "all but the N youngest": a load waited for inside the store
       // passes drains every store issued before it.  (The per-pass epilogue above does that eight times per
@@ -603,7 +733,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       const bool col_ok = en < ep.N;
       const int enc = col_ok ? en : 0;
       const int er = em0 + (lane >> 3);            // row of pass p, half-row u: er + 16 p + 8 u
-      const bool pre_res = ep.R != nullptr;
+      constexpr bool HAS_PRE = PRE != PRE_NONE, pre_res = PRE == PRE_RES;
       bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: lane-linear per piece
       const int tile_m0 = em0 - wr * 128;          // first row of the whole 256-row tile (wave-uniform)
       if constexpr (HAS_PRE) {
@@ -628,10 +758,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // row-vector lane needs, and 64 adds per tile instead of 128); same fp32 add, same result
       float bcol[2] = {0.f, 0.f};
       if (ep.bias) {
+        if constexpr (CONT) {                      // landed in the staging slice during K tile 0 (see above)
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(bcol[0]), "=&v"(bcol[1]) : "v"(bias_rd) : "memory");
+        } else {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int c = en0 + ni * 32 + (lane & 31);
-          bcol[ni] = ep.bias[c < ep.N ? c : 0];
+          for (int ni = 0; ni < 2; ++ni) {
+            const int c = en0 + ni * 32 + (lane & 31);
+            bcol[ni] = ep.bias[c < ep.N ? c : 0];
+          }
         }
       }
       float sc[8][2];
@@ -648,26 +783,27 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
             sc[p][u] = ep.row_scale[split ? (ml - ep.split_row) : (int)q1 * ep.rs_m1 + (ml - (int)q2 * ep.rs_d2) * ep.rs_m2];
           }
       }
-      if (more && tid == 0) pending = atomicAdd(my_ctr, 1);
-      // one wait for all of it; the empty asm statements make the loaded registers "used" here, so that hipcc's own
-      // wait for them lands before the prologue's DMA requests and not (as vmcnt(0)) behind them
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stamp(4);
-      asm volatile("" : "+v"(bcol[0]));
-      asm volatile("" : "+v"(bcol[1]));
-      if constexpr (HAS_SC) {
+      if constexpr (!CONT) {
+        if (more && tid == 0) pending = atomicAdd(my_ctr, 1);
+        // one wait for all of it; the empty asm statements make the loaded registers "used" here, so that hipcc's own
+        // wait for them lands before the prologue's DMA requests and not (as vmcnt(0)) behind them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
+        asm volatile("" : "+v"(bcol[0]));
+        asm volatile("" : "+v"(bcol[1]));
+        if constexpr (HAS_SC) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) { asm volatile("" : "+v"(sc[p][0])); asm volatile("" : "+v"(sc[p][1])); }
-      }
-      if constexpr (!HAS_PRE) {
-        if (more) { set_tile(t); prologue(); }      // ring is free: the next tile's first 7 regions land under the passes
+          for (int p = 0; p < 8; ++p) { asm volatile("" : "+v"(sc[p][0])); asm volatile("" : "+v"(sc[p][1])); }
+        }
+        if constexpr (!HAS_PRE) {
+          if (more) { set_tile(t, 0); m0 = m0s; n0 = n0s; prologue(); }   // ring is free: the next tile's first 7 regions land under the passes
+        }
       }
       stamp(5);
       const TileMap cm = make_tile_map(ep.cmap, tile_m0);
       // The staged rows (and the residual rows) are read back with inline-asm ds_read + lgkmcnt(0) in ONE statement:
       // hipcc orders any ds_read IT emits behind every LDS-DMA in flight (`s_waitcnt vmcnt(0)`), i.e. pass 0 would
       // wait for the 14 prologue requests issued just above.
-      typedef __attribute__((address_space(3))) char lds_char;
       const unsigned stg_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) +
                                                                     ((lane >> 3) * PP_STG_LD + (lane & 7) * 8) * 4);
       const unsigned pre_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(pre_lds) + lane * 16);
@@ -703,11 +839,24 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           const int m = er + 16 * (p_) + 8 * u;                                                         \
           const bool ok = col_ok && m < ep.M && dbg != 2;                                               \
           const bool split = ep.split_row > 0 && m >= ep.split_row;                                     \
-          if (ep.act == 1) {                                                                            \
-            if (ep.C2 && ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, v[u]);  \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] = gelu_erf(v[u][j]);                  \
+          if constexpr (HAS_ACT) {                                                                      \
+            if (ep.act == 2) {                     /* GELU, second output = its derivative */          \
+              float gp[8];                                                                              \
+              _Pragma("unroll") for (int j = 0; j < 8; ++j) gelu_erf_both(v[u][j], v[u][j], gp[j]);     \
+              if (ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, gp);           \
+            } else {                                                                                    \
+              if (ep.C2 && ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, v[u]); \
+              _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] = gelu_erf(v[u][j]);                \
+            }                                                                                           \
           }                                                                                             \
-          if (HAS_PRE && !pre_res) {                                                                    \
+          if constexpr (PRE == PRE_MUL) {          /* the block holds gelu'(x) itself */                \
+            const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+              v[u][2 * j] *= __uint_as_float(w[j] << 16);                                               \
+              v[u][2 * j + 1] *= __uint_as_float(w[j] & 0xffff0000u);                                   \
+            }                                                                                           \
+          }                                                                                             \
+          if constexpr (PRE == PRE_DGELU) {                                                             \
             const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
               v[u][2 * j] *= gelu_erf_grad(__uint_as_float(w[j] << 16));                                \
@@ -715,7 +864,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
             }                                                                                           \
           }                                                                                             \
           if constexpr (HAS_SC) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] *= sc[p_][u]; } \
-          if (HAS_PRE && pre_res && !split) {                                                           \
+          if (pre_res && !split) {                                                                      \
             const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
               v[u][2 * j] += __uint_as_float(w[j] << 16);                                               \
@@ -734,25 +883,32 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       stamp(6);
       if constexpr (HAS_PRE) {
         __builtin_amdgcn_s_barrier();               // every wave has read its residual block: the ring may be refilled
-        if (more) { set_tile(t); prologue(); }
+        if (more) { set_tile(t, 0); m0 = m0s; n0 = n0s; prologue(); }
       }
       stamp(7);
       ++trace_tile;
       if (!more) break;
+      if constexpr (CONT) {                         // the next tile's K tiles 0 and 1 are already in the ring
+        abase += (long)nk * (PP_BK * 2); bbase += (long)nk * (PP_BK * 2);
+        m0 = m0s; n0 = n0s;
+        par ^= nk & 1;
+        t = t_next; t_next = t_nn;
+      }
     }
   }
   check_out();
+#undef PP_KTILE
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_MMA
 #undef PP_BAR
 }
 
-template <bool EPI2, bool HAS_PRE, bool HAS_SC>
+template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT>
 static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st, const Options& cfg) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         PP_LDS_BYTES);
     attr_set = true;
   }
@@ -763,19 +919,29 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   if (!cfg.pp_cg && cg < 3) cg = 3;
   if (!cfg.pp_cg && cg > 6) cg = 6;
   if (cg < 1) cg = 1;
-  hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, HAS_PRE, HAS_SC>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
+  hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
                      (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, cg,
-                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, ep);
+                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, cfg.pp_touch, ep);
   return check_launch("gemm_nt_pp");
 }
 
 static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st) {
   const Options& cfg = options();
-  if (cfg.pp_epi == 1) return launch_pp_t<false, false, false>(d, ep, st, cfg);
-  // specialised on what the epilogue has to read, so that a plain GEMM carries no prefetch registers
-  const bool pre = d->R || d->dgelu_in, sc = d->row_scale != nullptr;
-  if (pre) return sc ? launch_pp_t<true, true, true>(d, ep, st, cfg) : launch_pp_t<true, true, false>(d, ep, st, cfg);
-  return sc ? launch_pp_t<true, false, true>(d, ep, st, cfg) : launch_pp_t<true, false, false>(d, ep, st, cfg);
+  if (cfg.pp_epi == 1) return launch_pp_t<false, PRE_NONE, false, false, false>(d, ep, st, cfg);   // generic epilogue: any combination
+  // specialised on what the epilogue has to read, so that a plain GEMM carries no prefetch registers and no branch
+  // sits inside the passes; the activation and the GELU' / multiplier inputs are only instantiated without
+  // residual / row scale (the FFN's Linears: vtx_gemm_nt routes other combinations to the non-persistent kernels)
+  const bool sc = d->row_scale != nullptr;
+  // continuous flow: row maps that cross a group boundary at most once per 256-row tile (what its 32-bit row
+  // offsets assume)
+  const bool cont = cfg.pp_cont != 0 && (d->amap.grp <= 0 || d->amap.grp >= 256);
+  if (d->act) return cont ? launch_pp_t<true, PRE_NONE, false, true, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, true, false>(d, ep, st, cfg);
+  if (d->dgelu_in)
+    return d->dgelu_kind == 1 ? launch_pp_t<true, PRE_MUL, false, false, false>(d, ep, st, cfg)
+                              : launch_pp_t<true, PRE_DGELU, false, false, false>(d, ep, st, cfg);
+  if (d->R) return sc ? launch_pp_t<true, PRE_RES, true, false, false>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, false, false, false>(d, ep, st, cfg);
+  if (sc) return launch_pp_t<true, PRE_NONE, true, false, false>(d, ep, st, cfg);
+  return cont ? launch_pp_t<true, PRE_NONE, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, false, false>(d, ep, st, cfg);
 }
 
 // ------------------------------------------------------------------ fp32 kernel
@@ -897,18 +1063,20 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
                   d->ldc % vec == 0, VTX_EALIGN, "gemm_nt: operands must be 16-byte aligned");
   VTX_REQUIRE(!d->bias || aligned16(d->bias), VTX_EALIGN, "gemm_nt: bias not aligned");
   VTX_REQUIRE(!d->R || (aligned16(d->R) && d->ldr % vec == 0), VTX_EALIGN, "gemm_nt: residual not aligned");
-  VTX_REQUIRE(!(d->act == 1 && d->C2) || (aligned16(d->C2) && d->ldc2 % vec == 0), VTX_EALIGN, "gemm_nt: C2 not aligned");
+  VTX_REQUIRE(!(d->act && d->C2) || (aligned16(d->C2) && d->ldc2 % vec == 0), VTX_EALIGN, "gemm_nt: C2 not aligned");
+  VTX_REQUIRE(d->act != 2 || d->C2, VTX_EINVAL, "gemm_nt: act 2 needs C2 (the derivative output)");
+  VTX_REQUIRE(d->dgelu_kind == 0 || d->dgelu_kind == 1, VTX_EINVAL, "gemm_nt: bad dgelu_kind %d", d->dgelu_kind);
   VTX_REQUIRE(!d->dgelu_in || (aligned16(d->dgelu_in) && d->ld_dgelu % vec == 0), VTX_EALIGN, "gemm_nt: dgelu_in not aligned");
   VTX_REQUIRE(d->split_row <= 0 || (d->Csplit && aligned16(d->Csplit) && d->ldsplit % vec == 0), VTX_EINVAL,
               "gemm_nt: split_row needs an aligned Csplit");
   VTX_REQUIRE(!d->row_scale || (d->rs_d1 > 0 && d->rs_d2 > 0), VTX_EINVAL, "gemm_nt: row_scale divisors must be > 0");
-  VTX_REQUIRE(d->act == 0 || d->act == 1, VTX_EINVAL, "gemm_nt: bad act %d", d->act);
+  VTX_REQUIRE(d->act >= 0 && d->act <= 2, VTX_EINVAL, "gemm_nt: bad act %d", d->act);
 
   EpiParams ep;
   ep.M = d->M; ep.N = d->N;
   ep.C = d->C; ep.ldc = d->ldc; ep.cmap = d->cmap;
   ep.bias = d->bias; ep.act = d->act; ep.C2 = d->C2; ep.ldc2 = d->ldc2;
-  ep.dgelu_in = d->dgelu_in; ep.ld_dgelu = d->ld_dgelu;
+  ep.dgelu_in = d->dgelu_in; ep.ld_dgelu = d->ld_dgelu; ep.dgelu_kind = d->dgelu_kind;
   ep.row_scale = d->row_scale; ep.rs_d1 = d->rs_d1; ep.rs_m1 = d->rs_m1; ep.rs_d2 = d->rs_d2; ep.rs_m2 = d->rs_m2;
   ep.R = d->R; ep.ldr = d->ldr; ep.rmap = d->rmap; ep.r_period = d->r_period;
   ep.split_row = d->split_row; ep.Csplit = d->Csplit; ep.ldsplit = d->ldsplit;
@@ -930,7 +1098,12 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
     const int nkt = d->K / BK16;
     // the ping-pong kernel prefetches the residual and the GELU' input into the same registers, and keeps its
     // tile counters in the caller's workspace
-    const bool pp_ok = dma_ok && nkt >= 2 && !(d->R && d->dgelu_in) && d->workspace && d->ws_bytes >= vtx_gemm_nt_workspace();
+    const bool combo_ok = o.pp_epi == 1 || ((!d->act || !(d->R || d->dgelu_in || d->row_scale)) &&
+                                            (!d->dgelu_in || !(d->R || d->row_scale)));
+    // 32-bit byte offsets inside a tile: its 256 rows (plus the rows a row map skips inside it) must span < 2 GB
+    const long span_rows = 256 + (d->amap.grp > 0 ? (256 / d->amap.grp + 2) * (long)(d->amap.skip > 0 ? d->amap.skip : 0) : 0);
+    const bool span_ok = span_rows * d->lda * 2 < (1L << 31) && 256L * d->ldb * 2 < (1L << 31) && d->amap.skip >= 0;
+    const bool pp_ok = dma_ok && nkt >= 2 && combo_ok && span_ok && d->workspace && d->ws_bytes >= vtx_gemm_nt_workspace();
     if (variant == NT_PP256 && pp_ok) return launch_pp(d, ep, st);
     if (dma_ok && nkt >= 3 && (variant == NT_RING256X3)) return launch_ring<4, 3, 64>(d, ep, st);
     if (dma_ok && nkt >= 3 && (variant == NT_RING256X3K32 || variant == NT_PP256)) return launch_ring<4, 3, 32>(d, ep, st);

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ('C', C.c_void_p), ('ldc', C.c_long), ('cmap', RowMap),
         ('bias', C.c_void_p),
         ('act', C.c_int), ('C2', C.c_void_p), ('ldc2', C.c_long),
-        ('dgelu_in', C.c_void_p), ('ld_dgelu', C.c_long),
+        ('dgelu_in', C.c_void_p), ('ld_dgelu', C.c_long), ('dgelu_kind', C.c_int),
         ('row_scale', C.c_void_p),
         ('rs_d1', C.c_int), ('rs_m1', C.c_int), ('rs_d2', C.c_int), ('rs_m2', C.c_int),
         ('R', C.c_void_p), ('ldr', C.c_long), ('rmap', RowMap), ('r_period', C.c_int),

@@ -291,9 +291,12 @@ class FFNFn(torch.autograd.Function):
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         w1c, w1T = weights(w1, dtp, any(ctx.needs_input_grad))
+        # the second output is gelu'(pre-activation), not the pre-activation: it is all the backward needs of it
+        # (transformer.py:503 nn.GELU), computed from the same erf / exp evaluation, and the backward's epilogue
+        # becomes one multiply instead of an erf + exp per element
         h = _empty((M, Hd), x)
         g = _empty((M, Hd), x)
-        ops.gemm_nt(xn, w1c, g, M, Hd, D, bias=b1, act=1, C2=h)
+        ops.gemm_nt(xn, w1c, g, M, Hd, D, bias=b1, act=2, C2=h)
         w2c, w2T = weights(w2, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
         ops.gemm_nt(g, w2c, out, M, D, Hd, bias=b2, row_scale=scale_vec, rs=(rows_per, 1, 1, 0), R=x)
@@ -318,7 +321,7 @@ class FFNFn(torch.autograd.Function):
             dz = dout
         d_w2, d_b2 = ops.gemm_tn(dz, g, M, D, Hd, want_colsum=True)
         dh = _empty((M, Hd), x)
-        ops.gemm_nt(dz, w2T, dh, M, Hd, D, dgelu_in=h)
+        ops.gemm_nt(dz, w2T, dh, M, Hd, D, dgelu_in=h, dgelu_kind=1)
         d_w1, d_b1 = ops.gemm_tn(dh, xn, M, Hd, D, want_colsum=True)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dh, w1T, dxn, M, D, Hd)

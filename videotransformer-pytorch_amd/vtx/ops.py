@@ -147,7 +147,7 @@ def _gemm_nt_workspace(device):
 
 
 def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=IDENT, bias=None, act=0,
-            C2=None, dgelu_in=None, row_scale=None, rs=(1, 0, 1, 0), R=None, ldr=None, rmap=IDENT,
+            C2=None, dgelu_in=None, dgelu_kind=0, row_scale=None, rs=(1, 0, 1, 0), R=None, ldr=None, rmap=IDENT,
             r_period=0, split_row=0, Csplit=None):
     """C = epilogue(A[M,K] @ B[N,K]^T); see vtx_gemm_nt in include/vtx.h."""
     need_cuda(A, B, Cout)
@@ -160,7 +160,7 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
     d.C = ptr(Cout); d.ldc = N if ldc is None else ldc; d.cmap = cmap
     d.bias = ptr(_f32(bias)); d.act = act
     d.C2 = ptr(C2); d.ldc2 = N
-    d.dgelu_in = ptr(dgelu_in); d.ld_dgelu = N
+    d.dgelu_in = ptr(dgelu_in); d.ld_dgelu = N; d.dgelu_kind = int(dgelu_kind)
     d.row_scale = ptr(_f32(row_scale)); d.rs_d1, d.rs_m1, d.rs_d2, d.rs_m2 = [int(v) for v in rs]
     d.R = ptr(R); d.ldr = (N if ldr is None else ldr); d.rmap = rmap; d.r_period = int(r_period)
     d.split_row = int(split_row); d.Csplit = ptr(Csplit); d.ldsplit = N
@@ -177,10 +177,10 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
         tags = ''
         if C2 is not None:
             nb += M * N * es
-            tags += '+preact'
+            tags += '+preact' if act == 1 else "+gelu'out"
         if dgelu_in is not None:
             nb += M * N * es
-            tags += "+gelu'"
+            tags += "+gelu'" if dgelu_kind == 0 else '+mul'
         if R is not None:
             nb += (min(M, r_period) if r_period else M) * N * es
             tags += '+res'
