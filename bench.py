@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true', help='skip the instrumented per-kernel-class pass')
     ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--no-direct-grads', action='store_true',
+                    help='parameter gradients through autograd accumulation instead of straight into the buckets')
     ap.add_argument('--optimizer', default='fused', choices=['fused', 'torch'],
                     help='fused = vtx multi-tensor SGD-nesterov kernel; torch = torch.optim.SGD (foreach)')
     return ap.parse_args()
@@ -229,7 +231,7 @@ def main():
     dp.broadcast_parameters(head)
     # gradients live in flat per-layer buckets: the all-reduce units for N > 1 and the multi-tensor
     # optimizer's operands for any N
-    buckets = dp.GradBuckets(params, force_comm=force_dp)
+    buckets = dp.GradBuckets(params, force_comm=force_dp, direct=not args.no_direct_grads)
     opt = None
     if not args.no_optimizer:
         if args.optimizer == 'fused':

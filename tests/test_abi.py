@@ -121,3 +121,15 @@ def test_options_api():
     for name, value in (('gemm_nt', 'nope'), ('no_such_switch', '1'), ('pp_grid', '7')):
         with pytest.raises(vtx.VtxError):
             vtx.set_option(name, value)
+
+
+def test_continuous_flow_draw_register_is_private():
+    """The persistent GEMM's continuous flow draws tile indices with an inline-asm atomic hipcc does not track; the
+    generated code must leave its result register alone until the counted wait (tools/check_isa.py)."""
+    import sys
+    obj = os.path.join(ROOT, 'videotransformer-pytorch_amd', 'csrc', '_obj', 'gemm_nt.o')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_isa
+    if not os.path.exists(obj) or not os.path.exists(check_isa.OBJDUMP):
+        pytest.skip('needs the compiled object of csrc/gemm_nt.hip and llvm-objdump')
+    assert check_isa.check(obj) == []

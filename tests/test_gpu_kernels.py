@@ -316,9 +316,14 @@ def test_gemm_nt_pp_continuous_flow(N, K, vtx_opts):
     W, bias = rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
     Xd, Wd, bd = dev(X, dtype), dev(W, dtype), dev(bias)
     Xq, Wq = q(X, dtype), q(W, dtype)
+    sv = (torch.rand(M // T, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7
     cases = {
         'plain': (dict(), Xq.reshape(-1, K)[:M] @ Wq.t()),
         'bias+map': (dict(amap=tm, bias=bd), Xq[:, 1:].reshape(M, K) @ Wq.t() + bias.double()),
+        'bias+map+scale': (dict(amap=tm, bias=bd, row_scale=dev(sv), rs=(T, 1, 1, 0)),
+                           (Xq[:, 1:].reshape(M, K) @ Wq.t() + bias.double()) * sv.double().repeat_interleave(T)[:, None]),
+        'scale': (dict(row_scale=dev(sv), rs=(T, 1, 1, 0)),
+                  (Xq.reshape(-1, K)[:M] @ Wq.t()) * sv.double().repeat_interleave(T)[:, None]),
     }
     pre = Xq[:, 1:].reshape(M, K) @ Wq.t() + bias.double()
     preq = pre.clone().requires_grad_(True)

@@ -210,6 +210,52 @@ def test_block_recompute_gives_identical_gradients():
         assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
+def test_direct_parameter_gradients_match_autograd_accumulation():
+    """vtx.dp.GradBuckets(direct=True): the weight-gradient reductions, bias column sums and LayerNorm backward
+    accumulate straight into the bucket views and fire the bucket hooks themselves (vtx.functions.set_direct_grads).
+    Same gradients bit for bit as autograd's accumulation, every bucket hook fires exactly once per backward, a
+    second backward into the same buffers accumulates (2x), and the recompute path works the same way."""
+    import vtx
+    import video_transformer as V
+    from vtx import dp, functions
+    for prec in ('bf16', 'fp32'):
+        vtx.set_precision(prec)
+        m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
+        x = synth.synth_clip(3, 4, 3, 64, 64, seed=2)
+        _, ref = _train_step(m, x, 11, 128)
+        ref = {k: v.clone() for k, v in ref.items()}
+        for recompute in (False, True):
+            vtx.set_recompute(recompute)
+            buckets = dp.GradBuckets(list(m.parameters()), bucket_bytes=64 << 10, direct=True)
+            try:
+                assert functions.direct_grads_enabled()
+                buckets.zero()
+                m.train()
+                torch.manual_seed(11)
+                w = (synth_tensor('loss_w', (128,), 0) * 10.0).to(DEV)
+                (m(x.to(DEV)) * w).sum().backward()
+                torch.cuda.synchronize()
+                assert all(b['pending'] == 0 for b in buckets.buckets), [b['pending'] for b in buckets.buckets]
+                for k, p in m.named_parameters():
+                    assert torch.equal(p.grad, ref[k]), f'{prec} recompute={recompute}: {k}'
+            finally:
+                buckets.remove()
+                vtx.set_recompute(False)
+            assert not functions.direct_grads_enabled()
+        # accumulation over two backward passes into caller-owned buffers (no buckets, no hooks)
+        functions.set_direct_grads(True)
+        try:
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)
+            for _ in range(2):
+                torch.manual_seed(11)
+                (m(x.to(DEV)) * w).sum().backward()
+            for k, p in m.named_parameters():
+                check(f'{prec} two backward passes {k}', p.grad.cpu(), 2 * ref[k].cpu(), 1e-6)
+        finally:
+            functions.set_direct_grads(False)
+
+
 def test_batch_and_length_properties():
     """Size-independent properties at full width: clips are independent (a clip's output does not
     depend on its batch neighbours) and eval forward is deterministic."""

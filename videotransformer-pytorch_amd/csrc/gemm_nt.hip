@@ -443,7 +443,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     if (tid == 0) v = atomicAdd(my_ctr, 1);
     return publish(v);
   };
-  static_assert(!CONT || (EPI2 && PRE == PRE_NONE && !HAS_SC), "the continuous flow needs an idle operand ring in the epilogue");
+  static_assert(!CONT || (EPI2 && PRE == PRE_NONE), "the continuous flow needs an idle operand ring in the epilogue");
   // Request addresses = a wave-uniform 64-bit base per operand (first byte of the tile's A rows / B rows, in scalar
   // registers, advanced by scalar adds) + a 32-bit byte offset per lane and piece: the DMA instruction takes both
   // (saddr + voffset), so a request costs no vector ALU work inside the MFMA sections and the eight per-lane
@@ -614,12 +614,26 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     stamp(1);
     if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
     if constexpr (CONT) {
-      // bias of this wave's 64 columns -> staging slice (+256 B): lane l fetches column en0 + l
+      // bias of this wave's 64 columns -> staging slice (+256 B): lane l fetches column en0 + l;
+      // DropPath scales of its 128 rows -> staging slice (+512 B): lane l fetches the scales of rows l and 64 + l
       auto bias_dma = [&]() {
         if (ep.bias) {
           const int c = n0 + wc * 64 + lane;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ep.bias + (c < ep.N ? c : 0)),
                                            (__attribute__((address_space(3))) void*)(stg + 64), 4, 0, 0);
+        }
+        if constexpr (HAS_SC) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int ml = m0 + wr * 128 + h * 64 + lane;
+            if (ml >= ep.M) ml = ep.M - 1;
+            const bool split = ep.split_row > 0 && ml >= ep.split_row;
+            const unsigned q1 = fast_div((unsigned)ml, ep.rs_magic1, ep.rs_shift1);
+            const unsigned q2 = fast_div((unsigned)ml, ep.rs_magic2, ep.rs_shift2);
+            const int idx = split ? (ml - ep.split_row) : (int)q1 * ep.rs_m1 + (ml - (int)q2 * ep.rs_d2) * ep.rs_m2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ep.row_scale + idx),
+                                             (__attribute__((address_space(3))) void*)(stg + 128 + h * 64), 4, 0, 0);
+          }
         }
       };
       // The draw.  hipcc cannot be allowed to see it: (a) its atomic optimizer aggregates a uniform-address atomic over
@@ -770,7 +784,20 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         }
       }
       float sc[8][2];
-      if constexpr (HAS_SC) {
+      if constexpr (HAS_SC && CONT) {              // landed in the staging slice during K tile 0: row r of the block at word 128 + r
+        const unsigned sc_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 512 + (lane >> 3) * 4);
+        asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:32\n\tds_read_b32 %2, %16 offset:64\n\t"
+                     "ds_read_b32 %3, %16 offset:96\n\tds_read_b32 %4, %16 offset:128\n\tds_read_b32 %5, %16 offset:160\n\t"
+                     "ds_read_b32 %6, %16 offset:192\n\tds_read_b32 %7, %16 offset:224\n\tds_read_b32 %8, %16 offset:256\n\t"
+                     "ds_read_b32 %9, %16 offset:288\n\tds_read_b32 %10, %16 offset:320\n\tds_read_b32 %11, %16 offset:352\n\t"
+                     "ds_read_b32 %12, %16 offset:384\n\tds_read_b32 %13, %16 offset:416\n\tds_read_b32 %14, %16 offset:448\n\t"
+                     "ds_read_b32 %15, %16 offset:480\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(sc[0][0]), "=&v"(sc[0][1]), "=&v"(sc[1][0]), "=&v"(sc[1][1]), "=&v"(sc[2][0]), "=&v"(sc[2][1]),
+                       "=&v"(sc[3][0]), "=&v"(sc[3][1]), "=&v"(sc[4][0]), "=&v"(sc[4][1]), "=&v"(sc[5][0]), "=&v"(sc[5][1]),
+                       "=&v"(sc[6][0]), "=&v"(sc[6][1]), "=&v"(sc[7][0]), "=&v"(sc[7][1])
+                     : "v"(sc_rd) : "memory");
+      }
+      if constexpr (HAS_SC && !CONT) {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -940,7 +967,7 @@ static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st
     return d->dgelu_kind == 1 ? launch_pp_t<true, PRE_MUL, false, false, false>(d, ep, st, cfg)
                               : launch_pp_t<true, PRE_DGELU, false, false, false>(d, ep, st, cfg);
   if (d->R) return sc ? launch_pp_t<true, PRE_RES, true, false, false>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, false, false, false>(d, ep, st, cfg);
-  if (sc) return launch_pp_t<true, PRE_NONE, true, false, false>(d, ep, st, cfg);
+  if (sc) return cont ? launch_pp_t<true, PRE_NONE, true, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, true, false, false>(d, ep, st, cfg);
   return cont ? launch_pp_t<true, PRE_NONE, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, false, false>(d, ep, st, cfg);
 }
 

@@ -20,8 +20,16 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, comm_dtype=None, force_comm=False):
+    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, comm_dtype=None, force_comm=False,
+                 direct=False):
+        """direct=True: the block kernels accumulate parameter gradients straight into the bucket views (no
+        per-parameter `grad += new` kernels; see vtx.functions.set_direct_grads) -- a process-wide switch that
+        stays on until set_direct_grads(False) or remove()."""
         self.group = process_group
+        self.direct = bool(direct)
+        if self.direct:
+            from . import functions
+            functions.set_direct_grads(True)
         self.force_comm = force_comm            # issue the collectives even in a 1-rank group (exercises RCCL)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype            # e.g. torch.bfloat16 to halve xGMI bytes (lossy)
@@ -106,6 +114,10 @@ class GradBuckets:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self.direct:
+            from . import functions
+            functions.set_direct_grads(False)
+            self.direct = False
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -49,6 +49,63 @@ def clear_weight_cache():
     _wcache.clear()
 
 
+# ---- direct parameter gradients ---------------------------------------------------------------------
+# autograd accumulates a returned parameter gradient with one `grad += new` kernel per parameter (and the
+# Functions below used to zero-fill the LayerNorm gradients they accumulate into): ~370 five-microsecond launches
+# per TimeSformer-B step.  With direct gradients on, the weight-gradient GEMM's reduction, its fused bias
+# column sums and the LayerNorm backward accumulate straight into ``param.grad`` (same fp32 `+=`), the Function
+# returns None for that parameter and calls the parameter's post-accumulate-grad hooks itself (the
+# data-parallel bucket hooks of vtx.dp).  Opt-in (vtx.dp.GradBuckets(..., direct=True) turns it on): it needs
+# pre-allocated contiguous fp32 ``.grad`` buffers, and only ``loss.backward()`` sees these gradients --
+# ``torch.autograd.grad`` and tensor hooks on the parameters do not.
+_direct = False
+
+
+def set_direct_grads(on):
+    global _direct
+    _direct = bool(on)
+
+
+def direct_grads_enabled():
+    return _direct
+
+
+def _sink(p):
+    if not _direct or p is None:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
+def _fire(*params):
+    for p in params:
+        hooks = getattr(p, '_post_accumulate_grad_hooks', None)
+        if hooks:
+            for h in list(hooks.values()):
+                h(p)
+
+
+def _linear_grads(w, b, A, Bm, M, N1, N2, **kw):
+    """(d_weight, d_bias) of a Linear out of the two GEMM operands; (None, None) when they went straight into
+    w.grad / b.grad."""
+    gw, gb = _sink(w), _sink(b)
+    if gw is not None and gb is not None:
+        ops.gemm_tn(A, Bm, M, N1, N2, out=gw.view(N1, N2), accumulate=True, colsum_out=gb, colsum_accumulate=True, **kw)
+        _fire(w, b)
+        return None, None
+    return ops.gemm_tn(A, Bm, M, N1, N2, want_colsum=True, **kw)
+
+
+def _ln_grad_buffers(ln_w, ln_b, D, device):
+    """Buffers vtx_layernorm_bwd accumulates d_gamma / d_beta into: the parameters' own .grad (direct), else zeros."""
+    gw, gb = _sink(ln_w), _sink(ln_b)
+    if gw is not None and gb is not None:
+        return gw, gb, True
+    return (torch.zeros(D, dtype=torch.float32, device=device), torch.zeros(D, dtype=torch.float32, device=device), False)
+
+
 def _empty(shape, like, dtype=None):
     return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
 
@@ -97,11 +154,13 @@ class TimeAttnFn(torch.autograd.Function):
                               scale_vec if scale_vec is not None else x.new_empty(0),
                               *[t for t in (wqT, wpT, wtT) if t is not None])
         ctx.cfg = (T, heads, scale_vec is not None)
+        ctx.params = (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, ln_w, mean, rstd, xn, qkv, o, lse, a, sv, wqT, wpT, wtT = ctx.saved_tensors
+        p_ln_w, p_ln_b, p_qkv_w, p_qkv_b, p_proj_w, p_proj_b, p_tfc_w, p_tfc_b = ctx.params
         T, heads, has_scale = ctx.cfg
         sv = sv if has_scale else None
         dout = _chk(dout)
@@ -113,24 +172,26 @@ class TimeAttnFn(torch.autograd.Function):
         tm = ops.tokmap(N)
         dtp = x.dtype
         # temporal_fc
-        d_tfc_w, d_tfc_b = ops.gemm_tn(dout, a, M, D, D, amap=tm, want_colsum=True)
+        d_tfc_w, d_tfc_b = _linear_grads(p_tfc_w, p_tfc_b, dout, a, M, D, D, amap=tm)
         da = _empty((M, D), x)
         ops.gemm_nt(dout, wtT, da, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
         # proj
-        d_proj_w, d_proj_b = ops.gemm_tn(da, o, M, D, D, want_colsum=True)
+        d_proj_w, d_proj_b = _linear_grads(p_proj_w, p_proj_b, da, o, M, D, D)
         do = _empty((M, D), x)
         ops.gemm_nt(da, wpT, do, M, D, D)
         # attention core
         dqkv = _empty((M, 3 * D), x)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, T, heads, hd, hd ** -0.5)
-        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M, 3 * D, D, want_colsum=True)
+        d_qkv_w, d_qkv_b = _linear_grads(p_qkv_w, p_qkv_b, dqkv, xn, M, 3 * D, D)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
         # LayerNorm + residual
         dx = torch.empty_like(x)
-        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
-        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        if direct:
+            _fire(p_ln_w, p_ln_b)
+            d_ln_w = d_ln_b = None
         ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
         return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None)
 
@@ -177,11 +238,13 @@ class SpaceAttnFn(torch.autograd.Function):
                               scale_vec if scale_vec is not None else x.new_empty(0),
                               *[t for t in (wqT, wpT) if t is not None])
         ctx.cfg = (T, heads, scale_vec is not None)
+        ctx.params = (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, ln_w, mean, rstd, xn, qkv, o, lse, sv, wqT, wpT = ctx.saved_tensors
+        p_ln_w, p_ln_b, p_qkv_w, p_qkv_b, p_proj_w, p_proj_b = ctx.params
         T, heads, has_scale = ctx.cfg
         sv = sv if has_scale else None
         dout = _chk(dout)
@@ -194,7 +257,7 @@ class SpaceAttnFn(torch.autograd.Function):
         dtp = x.dtype
         da = _empty((Mo, D), x)
         ops.space_grad_prep(dout, sv, da, B, T, P, D)
-        d_proj_w, d_proj_b = ops.gemm_tn(da, o, Mo, D, D, want_colsum=True)
+        d_proj_w, d_proj_b = _linear_grads(p_proj_w, p_proj_b, da, o, Mo, D, D)
         do = _empty((Mo, D), x)
         ops.gemm_nt(da, wpT, do, Mo, D, D)
         dqkv = _empty((M1, 3 * D), x)
@@ -202,13 +265,15 @@ class SpaceAttnFn(torch.autograd.Function):
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_SPACE, B * T, P + 1, heads, hd, hd ** -0.5, B, T, P,
                      dqkv_cls=dqkv_cls)
         ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, N1)
-        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xn, M1, 3 * D, D, want_colsum=True)
+        d_qkv_w, d_qkv_b = _linear_grads(p_qkv_w, p_qkv_b, dqkv, xn, M1, 3 * D, D)
         dxn = _empty((M1, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M1, D, 3 * D)
         dx = torch.empty_like(x)
-        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
-        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M1, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        if direct:
+            _fire(p_ln_w, p_ln_b)
+            d_ln_w = d_ln_b = None
         return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None)
 
 
@@ -304,11 +369,13 @@ class FFNFn(torch.autograd.Function):
                               scale_vec if scale_vec is not None else x.new_empty(0),
                               *[t for t in (w1T, w2T) if t is not None])
         ctx.cfg = (rows_per, scale_vec is not None, w1.shape[0])
+        ctx.params = (ln_w, ln_b, w1, b1, w2, b2)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, ln_w, mean, rstd, xn, h, g, sv, w1T, w2T = ctx.saved_tensors
+        p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2 = ctx.params
         rows_per, has_scale, Hd = ctx.cfg
         dout = _chk(dout)
         D = x.shape[-1]
@@ -319,16 +386,18 @@ class FFNFn(torch.autograd.Function):
             ops.row_scale_copy(dout, dz, M, D, s=sv, rs=(rows_per, 1, 1, 0))
         else:
             dz = dout
-        d_w2, d_b2 = ops.gemm_tn(dz, g, M, D, Hd, want_colsum=True)
+        d_w2, d_b2 = _linear_grads(p_w2, p_b2, dz, g, M, D, Hd)
         dh = _empty((M, Hd), x)
         ops.gemm_nt(dz, w2T, dh, M, Hd, D, dgelu_in=h, dgelu_kind=1)
-        d_w1, d_b1 = ops.gemm_tn(dh, xn, M, Hd, D, want_colsum=True)
+        d_w1, d_b1 = _linear_grads(p_w1, p_b1, dh, xn, M, Hd, D)
         dxn = _empty((M, D), x)
         ops.gemm_nt(dh, w1T, dxn, M, D, Hd)
         dx = torch.empty_like(x)
-        d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
-        d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
         ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        if direct:
+            _fire(p_ln_w, p_ln_b)
+            d_ln_w = d_ln_b = None
         return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None)
 
 

@@ -193,13 +193,18 @@ def gemm_nt(A, B, Cout, M, N, K, lda=None, ldb=None, ldc=None, amap=IDENT, cmap=
 
 
 def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDENT, accumulate=False,
-            want_colsum=False):
-    """out[N1,N2] (fp32) (+)= sum_m A[m,:N1]^T B[m,:N2]; with want_colsum also returns
-    sum_m A[m,:N1] (the bias gradient that always accompanies a weight gradient)."""
+            want_colsum=False, colsum_out=None, colsum_accumulate=False):
+    """out[N1,N2] (fp32) (+)= sum_m A[m,:N1]^T B[m,:N2]; with want_colsum (or a colsum_out buffer, optionally
+    accumulated into) also returns sum_m A[m,:N1] (the bias gradient that always accompanies a weight gradient)."""
     need_cuda(A, B)
     if out is None:
         out = torch.empty(N1, N2, dtype=torch.float32, device=A.device)
-    cs = torch.empty(N1, dtype=torch.float32, device=A.device) if want_colsum else None
+    if colsum_out is not None:
+        need_cuda(colsum_out)
+        want_colsum = True
+        cs = colsum_out
+    else:
+        cs = torch.empty(N1, dtype=torch.float32, device=A.device) if want_colsum else None
     ws_bytes = _lib.load().vtx_gemm_tn_workspace(M, N1, N2)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
     d = GemmTnDesc()
@@ -208,7 +213,7 @@ def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDEN
     d.B = ptr(B); d.ldb = N2 if ldb is None else ldb; d.bmap = bmap
     d.C = ptr(out); d.ldc = N2; d.accumulate = int(bool(accumulate))
     d.workspace = ptr(ws); d.ws_bytes = ws_bytes
-    d.colsum = ptr(cs); d.colsum_accumulate = 0
+    d.colsum = ptr(cs); d.colsum_accumulate = int(bool(colsum_accumulate and colsum_out is not None))
     with _timed('gemm_tn', 2.0 * M * N1 * N2, M * (N1 + N2) * A.element_size() + N1 * N2 * 4, f'{M}x{N1}x{N2}'):
         call('vtx_gemm_tn', C.byref(d), stream())
     return (out, cs) if want_colsum else out
