@@ -61,7 +61,6 @@ const char* vtx_last_error_string(void);
  * "pp_epi" = integers ("pp_epi": 1 = per-pass epilogue of the persistent GEMM; 2 / 3 = timing diagnostics that skip
  * its stores / its LDS staging and produce WRONG output), "pp_cont" = 0|1 (continuous flow of the persistent GEMM: the
  * next tile's first K tiles are requested inside the current main loop; 1 by default, 0 = per-tile prologue; identical
- * results), "pp_touch" = k (k > 0: cache warm-up reads of the residual / multiplier block at K tile k; identical
  * results), "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown
  * name or value. */
 int vtx_set_option(const char* name, const char* value);

@@ -349,6 +349,41 @@ def test_gemm_nt_pp_continuous_flow(N, K, vtx_opts):
         check(f'cont gelu N={N} K={K} grid={grid}', outs[0][0].float().cpu(), torch.nn.functional.gelu(pre), 1e-2)
         check(f"cont gelu' N={N} K={K} grid={grid}", outs[0][1].float().cpu(), preq.grad, 1e-2)
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # residual-block flow (pp_cont=1 for epilogues that read a 128 x 64 block per wave: the block is requested inside
+    # the last two K tiles, the next tile's operands inside the passes) against the per-tile flow
+    R = rnd(B, 1 + Ntok, N, seed=6)
+    Rd, Rq = dev(R, dtype), q(R, dtype)
+    Hm = rnd(M, N, seed=8)
+    full = Xq[:, 1:].reshape(M, K) @ Wq.t() + bias.double()
+    sT = (torch.rand(B * T, generator=torch.Generator().manual_seed(9)) > 0.3).float() / 0.7
+    A2 = rnd(M + B * T, K, seed=10)                # rows [M, M + B*T): split rows (no residual, own output)
+    full2 = q(A2, dtype) @ Wq.t() + bias.double()
+    sc2 = torch.cat([sT.double().repeat_interleave(Ntok // T).reshape(B, T, P).transpose(1, 2).reshape(-1), sT.double()])
+    for grid in ('256', '8'):
+        vtx_opts('pp_grid', grid)
+        res = {}
+        for cont in ('1', '0'):
+            vtx_opts('pp_cont', cont)
+            o1 = torch.zeros(B, 1 + Ntok, N, dtype=dtype, device=DEV)
+            ops.gemm_nt(Xd, Wd, o1, M, N, K, amap=tm, cmap=tm, bias=bd, R=Rd, rmap=tm)
+            o2 = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
+            ops.gemm_nt(Xd, Wd, o2, M, N, K, amap=tm, bias=bd, R=Rd.view(-1, N)[:M].contiguous())
+            o3 = torch.full((M, N), float('nan'), dtype=dtype, device=DEV)
+            ops.gemm_nt(Xd, Wd, o3, M, N, K, amap=tm, dgelu_in=dev(Hm, dtype), dgelu_kind=1)
+            o4 = torch.zeros(B, 1 + Ntok, N, dtype=dtype, device=DEV)
+            c4 = torch.full((B * T, N), float('nan'), dtype=dtype, device=DEV)
+            ops.gemm_nt(dev(A2, dtype), Wd, o4, M + B * T, N, K, cmap=tm, bias=bd, row_scale=dev(sT), rs=(Ntok, T, T, 1),
+                        R=Rd, rmap=tm, split_row=M, Csplit=c4)
+            res[cont] = (o1, o2, o3, o4, c4)
+        tag = f'residual flow N={N} K={K} grid={grid}'
+        check(f'{tag} map+residual', res['1'][0].float().cpu()[:, 1:], full.reshape(B, Ntok, N) + Rq[:, 1:], 1e-2)
+        check(f'{tag} residual', res['1'][1].float().cpu(), full + Rq.reshape(-1, N)[:M], 1e-2)
+        check(f'{tag} multiplier', res['1'][2].float().cpu(), (Xq[:, 1:].reshape(M, K) @ Wq.t()) * q(Hm, dtype), 1e-2)
+        check(f'{tag} split tokens', res['1'][3].float().cpu()[:, 1:],
+              (full2[:M] * sc2[:M, None]).reshape(B, Ntok, N) + Rq[:, 1:], 1e-2)
+        check(f'{tag} split rows', res['1'][4].float().cpu(), full2[M:] * sc2[M:, None], 1e-2)
+        for a, b_ in zip(res['1'], res['0']):
+            assert torch.equal(a, b_), f'{tag}: the residual-block flow changes the result'
     # repeated launches on one stream (self-resetting counters, LDS hand-over words) stay identical
     vtx_opts('pp_cont', '1')
     vtx_opts('pp_grid', '256')
@@ -358,26 +393,6 @@ def test_gemm_nt_pp_continuous_flow(N, K, vtx_opts):
         ops.gemm_nt(Xd, Wd, C, M, N, K, amap=tm, bias=bd)
         first = C if first is None else first
         assert torch.equal(C, first)
-
-
-def test_gemm_nt_pp_touch_option(vtx_opts):
-    """pp_touch only warms the cache for the residual / multiplier block: results are unchanged."""
-    from vtx import ops
-    dtype = torch.bfloat16
-    vtx_opts('gemm_nt', 'pp256')
-    M, N, K = 5000, 768, 256
-    A, W, b = dev(rnd(M, K, seed=1), dtype), dev(rnd(N, K, seed=2) * K ** -0.5, dtype), dev(rnd(N, seed=3))
-    R = dev(rnd(M, N, seed=4), dtype)
-    outs = []
-    for touch in ('0', '1', '3'):
-        vtx_opts('pp_touch', touch)
-        C = torch.empty(M, N, dtype=dtype, device=DEV)
-        ops.gemm_nt(A, W, C, M, N, K, bias=b, R=R)
-        D = torch.empty(M, N, dtype=dtype, device=DEV)
-        ops.gemm_nt(A, W, D, M, N, K, dgelu_in=R, dgelu_kind=1)
-        outs.append((C, D))
-    for o in outs[1:]:
-        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -47,7 +47,6 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }
   if (strcmp(name, "pp_epi") == 0) { o.pp_epi = atoi(value); return VTX_OK; }
   if (strcmp(name, "pp_cont") == 0) { o.pp_cont = atoi(value) != 0; return VTX_OK; }
-  if (strcmp(name, "pp_touch") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_touch = g; return VTX_OK; }
   if (strcmp(name, "pp_trace") == 0) { o.pp_trace = strtoull(value, nullptr, 0); return VTX_OK; }
   return VTX_EINVAL;
 }
@@ -58,7 +57,7 @@ Options& options() {
     static const char* const env[][2] = {{"VTX_GEMM_NT", "gemm_nt"}, {"VTX_GEMM_TN", "gemm_tn"}, {"VTX_GEMM_NODMA", "gemm_nodma"},
                                          {"VTX_TN_SAFE", "tn_safe"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
                                          {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"},
-                                         {"VTX_GEMM_PP_CONT", "pp_cont"}, {"VTX_GEMM_PP_TOUCH", "pp_touch"}};
+                                         {"VTX_GEMM_PP_CONT", "pp_cont"}};
     for (const auto& e : env) {
       const char* v = getenv(e[0]);
       if (v && *v) set_option(d, e[1], v);       // an unparsable value keeps the default

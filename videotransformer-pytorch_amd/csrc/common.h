@@ -155,7 +155,6 @@ struct Options {
   int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing); 2 / 3 = diagnostics: no stores / no staging
   int pp_cont = 1;           // VTX_GEMM_PP_CONT: continuous flow of the persistent NT GEMM (next tile's first K tiles requested
                              // inside the current main loop) for epilogues that leave the operand ring alone; 0 = per-tile prologue
-  int pp_touch = 0;          // VTX_GEMM_PP_TOUCH: k > 0 = touch the residual / multiplier block's lines at K tile k (cache warm-up)
   unsigned long long pp_trace = 0;   // device address of a long long[256][8][8] timeline buffer (tools/pp_timeline.py), 0 = off
 };
 Options& options();

@@ -376,7 +376,7 @@ template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int CG, int* __restrict__ tile_ctr,
-    long long* __restrict__ trace, int dbg, int touch, EpiParams ep) {
+    long long* __restrict__ trace, int dbg, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -443,7 +443,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     if (tid == 0) v = atomicAdd(my_ctr, 1);
     return publish(v);
   };
-  static_assert(!CONT || (EPI2 && PRE == PRE_NONE), "the continuous flow needs an idle operand ring in the epilogue");
+  static_assert(!CONT || EPI2, "the continuous flows belong to the read-ahead epilogue");
+  constexpr bool CF = CONT && PRE == PRE_NONE;   // continuous operand flow: the epilogue leaves the ring alone
+  constexpr bool PF = CONT && PRE != PRE_NONE;   // residual-block flow: the ring receives the epilogue's block (see below)
   // Request addresses = a wave-uniform 64-bit base per operand (first byte of the tile's A rows / B rows, in scalar
   // registers, advanced by scalar adds) + a 32-bit byte offset per lane and piece: the DMA instruction takes both
   // (saddr + voffset), so a request costs no vector ALU work inside the MFMA sections and the eight per-lane
@@ -532,45 +534,49 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   __builtin_amdgcn_s_setprio(0);
 #define PP_BAR() __builtin_amdgcn_s_barrier()
 
-  // One 64-deep K tile = four phases.  N1_ / N2_: "K tile kt+1 / kt+2 exists" (in this tile, or -- continuous flow --
-  // as K tile 0 / 1 of the next tile); H1_ .. H4_: hooks inside the load sections of P1 .. P4.
+  // One 64-deep K tile = four phases.  ISS_: what the request slots of the four MFMA sections issue; H1_ .. H4_:
+  // hooks inside the load sections of P1 .. P4.
   // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section): inside a load
   // section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
-#define PP_KTILE(N1_, N2_, H1_, H2_, H3_, H4_)                                                              \
+#define PP_KTILE(E1_, E2_, W1_, W2_, ISS_, H1_, H2_, H3_, H4_)                                         \
     {                                                                                                  \
       const int buf = (kt & 1) ^ par;                                                                  \
-      const bool n1 = (N1_), n2 = (N2_);                                                               \
+      const bool e1 = (E1_), e2 = (E2_);           /* K tile kt+1 / kt+2 exists in this tile */        \
+      const bool w1 = (W1_), w2 = (W2_);           /* ... or its slots carry other requests: steady-state wait counts */ \
       /* P1: reads A0, B0; P2 will read B1(kt) */                                                      \
       PP_READ_A(buf, 0);                                                                               \
       PP_READ_B(buf, 1, fb0);                                                                          \
-      if (n1) wait_vmcnt<8>(); else wait_vmcnt<2>();                                                   \
+      if (w1) wait_vmcnt<8>(); else wait_vmcnt<2>();                                                   \
       H1_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
-      PP_MMA(0, 0, fb0, if (n1) issue(3, kt + 1));                                                     \
+      PP_MMA(0, 0, fb0, ISS_(3, kt + 1, e1));                                                          \
       PP_BAR();                                                                                        \
       /* P2: reads B1; P3 will read A1(kt) */                                                          \
       PP_READ_B(buf, 2, fb1);                                                                          \
-      if (n1) wait_vmcnt<8>(); else wait_vmcnt<0>();                                                   \
+      if (w1) wait_vmcnt<8>(); else wait_vmcnt<0>();                                                   \
       H2_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
-      PP_MMA(0, 1, fb1, if (n2) issue(0, kt + 2));                                                     \
+      PP_MMA(0, 1, fb1, ISS_(0, kt + 2, e2));                                                          \
       PP_BAR();                                                                                        \
       /* P3: reads A1 */                                                                               \
       PP_READ_A(buf, 3);                                                                               \
       H3_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
-      PP_MMA(2, 1, fb1, if (n2) issue(1, kt + 2));                                                     \
+      PP_MMA(2, 1, fb1, ISS_(1, kt + 2, e2));                                                          \
       PP_BAR();                                                                                        \
       /* P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1) */                           \
-      if (n2) wait_vmcnt<8>(); else if (n1) wait_vmcnt<4>();                                           \
+      if (w2) wait_vmcnt<8>(); else if (w1) wait_vmcnt<4>();                                           \
       H4_                                                                                              \
       PP_BAR();                                                                                        \
-      PP_MMA(2, 0, fb0, if (n2) issue(2, kt + 2));                                                     \
+      PP_MMA(2, 0, fb0, ISS_(2, kt + 2, e2));                                                          \
       PP_BAR();                                                                                        \
     }
+#define PP_ISS_COND(kind_, ktv_, ex_) if (ex_) issue(kind_, ktv_)          /* only K tiles of this tile */
+#define PP_ISS_ALWAYS(kind_, ktv_, ex_) issue(kind_, ktv_)                 /* continuous flow: the next tile's follow */
+#define PP_ISS_PRE(kind_, ktv_, ex_) if (ex_) issue(kind_, ktv_); else pre_slot(kind_, ktv_)   /* ... or the residual block */
 
   // Continuous flow (CONT: epilogues that leave the operand ring alone).  The K tiles of successive tiles form ONE
   // stream through the ring: the requests that the last two K tiles of a tile have no use for -- exactly the seven
@@ -590,9 +596,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   const int tend = xcount;
   if (t >= tend) { check_out(); return; }
   int t_next = tend, t_nn = tend;
-  if constexpr (CONT) t_next = next_tile();
+  if constexpr (CF) t_next = next_tile();
   int pending = 0;                               // index drawn ahead by lane 0 of the workgroup
-  if (EPI2 && !CONT && tid == 0) pending = atomicAdd(my_ctr, 1);
+  if (EPI2 && !CF && tid == 0) pending = atomicAdd(my_ctr, 1);
   set_tile(t, 0);
   m0 = m0s; n0 = n0s;
   prologue();
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 fa[2][4], fb0[4], fb1[4];
-    const bool more_c = CONT && t_next < tend;   // continuous flow: another tile follows this one
+    const bool more_c = CF && t_next < tend;     // continuous flow: another tile follows this one
     // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
     // younger request in flight (2 DMA instructions per region; issue order A0 B0 B1 A1 per K tile).
     stamp(0);
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     PP_BAR();
     stamp(1);
     if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
-    if constexpr (CONT) {
+    if constexpr (CF) {
       // bias of this wave's 64 columns -> staging slice (+256 B): lane l fetches column en0 + l;
       // DropPath scales of its 128 rows -> staging slice (+512 B): lane l fetches the scales of rows l and 64 + l
       auto bias_dma = [&]() {
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       if (more_c) {
         // every request of every K tile is unconditional here
         for (; kt < nk; ++kt) {
-          PP_KTILE(true, true,
+          PP_KTILE(true, true, true, true, PP_ISS_ALWAYS,
                    if (kt == 0) {
                      if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(my_ctr), "v"(one) : "memory");
                      bias_dma();
@@ -668,35 +674,61 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         }
       } else {
         for (; kt < nk; ++kt) {
-          PP_KTILE(kt + 1 < nk, kt + 2 < nk, if (kt == 0) bias_dma();, , , )
+          PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, PP_ISS_COND, if (kt == 0) bias_dma();, , , )
         }
       }
-    } else {
-      // Option pp_touch = k > 0: at K tile k every lane reads one word of two rows of the wave's residual / multiplier
-      // block (a row of the block is one 128-B line) into the idle staging slice, so that the block's lines are on
-      // their way into the cache hierarchy long before the epilogue requests all 128 KB of them at once.
-      auto touch_pre = [&]() {
-        if constexpr (EPI2 && PRE != PRE_NONE) {
-          const bool res = PRE == PRE_RES;
-          const bf16raw* const base = reinterpret_cast<const bf16raw*>(res ? ep.R : ep.dgelu_in);
-          const long ld = res ? ep.ldr : ep.ld_dgelu;
-          const int c = n0 + wc * 64 < ep.N ? n0 + wc * 64 : 0;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            int ml = m0 + wr * 128 + h * 64 + lane;
-            if (ml > ep.M - 1) ml = ep.M - 1;
-            long rr = ml;
-            if (res) {
-              const bool split = ep.split_row > 0 && ml >= ep.split_row;
-              rr = split ? 0 : (ep.r_period > 0 ? (long)(ml % ep.r_period) : map_row(ep.rmap, ml));
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + rr * ld + c),
-                                             (__attribute__((address_space(3))) void*)(stg + 128 + h * 64), 4, 0, 0);
-          }
+    } else if constexpr (PF) {
+      // Residual-block flow.  The epilogue's 128 x 64 block per wave (residual, GELU' input or multiplier: 128 KB per
+      // workgroup) used to be requested after the main loop into the idle ring -- every CU of the chip asking for its
+      // 128 KB at the same moment and waiting ~5.6 us for it -- and the next tile's operands could only be requested
+      // after the passes had read it.  Now the block takes the request slots the last two K tiles have no use for:
+      // slot (kind, K tile nk or nk + 1) = ring region s = 4 (ktv - nk) + kind, freed by the main loop in exactly that
+      // order, receives rows [16 s, 16 s + 16) of every wave's block (each wave its own 2 KB of the region, through its
+      // own two DMA instructions); regions 6 and 7 share the last slot.  Pass p of the epilogue reads region p, and the
+      // wave then requests ITS part of the next tile's operand region into the 2 KB it has just read: the standard
+      // seven-region prologue, spread over the passes, with no barrier (no wave touches another wave's part).
+      // Addresses as in set_tile(): a wave-uniform 64-bit base (the block row that holds the tile's first row) + 32-bit
+      // lane offsets; row maps with at most one group boundary per tile (the launcher routes others, and periodic
+      // residuals, to the per-tile flow).  Split rows (no residual) and rows beyond M read the tile's first row.
+      constexpr bool pres = PRE == PRE_RES;
+      const int pen = n0 + wc * 64 + (lane & 7) * 8;
+      const unsigned penc2 = pen < ep.N ? (unsigned)pen * 2u : 0u;
+      const unsigned pld2 = (unsigned)(pres ? ep.ldr : ep.ld_dgelu) * 2u;
+      // rows without a block row (beyond M; split rows, which take no residual) read the last row that has one
+      const int lastv = min(ep.M - 1, (pres && ep.split_row > 0) ? ep.split_row - 1 : 0x7fffffff);
+      const int m0c = min(m0, lastv);              // a tile of split rows only: everything reads row `lastv`
+      const TileMap prm = make_tile_map(ep.rmap, m0c);
+      const long pfirst = pres ? tile_map_row(prm, ep.rmap, m0c) : (long)m0c;
+      const char* pbase = reinterpret_cast<const char*>(pres ? ep.R : ep.dgelu_in) + pfirst * (long)pld2;
+      const int pbl = (pres && ep.rmap.grp > 0) ? prm.bound - m0c : 0x7fffffff;         // local row at which the skip starts
+      const int pskip = pres ? ep.rmap.skip : 0;
+      const int plast = lastv - m0c;               // >= 0
+      const int pl0 = (m0 - m0c) + wr * 128 + (lane >> 3);
+      auto pre_piece = [&](int j, bf16raw* dst) {  // rows 8j .. 8j+7 of the block: lane -> row 8j + lane/8, chunk lane%8
+        const int l = min(pl0 + 8 * j, plast);
+        const int lr = l + (l >= pbl ? pskip : 0);
+        const char* b = pbase;
+        asm volatile("" : "+s"(b));
+        dma16(reinterpret_cast<const bf16raw*>(b + ((unsigned)lr * pld2 + penc2)), dst);
+      };
+      auto pre_slot = [&](int kind, int ktv) {
+        const int s = (ktv - nk) * 4 + kind;
+        bf16raw* dst = lds + ((ktv & 1) ^ par) * PP_BUF + kind * PP_REGION + wave * 1024;
+        pre_piece(2 * s, dst);
+        pre_piece(2 * s + 1, dst + 512);
+        if (s == 6) {                              // region 7 = (A1, K tile nk + 1): read in P3, free from P4 on
+          bf16raw* dst7 = lds + ((ktv & 1) ^ par) * PP_BUF + 3 * PP_REGION + wave * 1024;
+          pre_piece(14, dst7);
+          pre_piece(15, dst7 + 512);
         }
       };
+      // every slot carries two requests as in the steady state: steady-state wait counts throughout
       for (int kt = 0; kt < nk; ++kt) {
-        PP_KTILE(kt + 1 < nk, kt + 2 < nk, if (touch > 0 && kt == touch) touch_pre();, , , )
+        PP_KTILE(kt + 1 < nk, kt + 2 < nk, true, true, PP_ISS_PRE, , , , )
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, PP_ISS_COND, , , , )
       }
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
@@ -727,7 +759,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // not an atomic round trip; the draw for the tile after it goes out below and returns under the
       // epilogue's own load latency.
       bool more = more_c;
-      if constexpr (!CONT) {
+      if constexpr (!CF) {
         t = publish(pending);
         more = t < tend;
       }
@@ -750,7 +782,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       constexpr bool HAS_PRE = PRE != PRE_NONE, pre_res = PRE == PRE_RES;
       bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: lane-linear per piece
       const int tile_m0 = em0 - wr * 128;          // first row of the whole 256-row tile (wave-uniform)
-      if constexpr (HAS_PRE) {
+      if constexpr (HAS_PRE && !PF) {
         const bf16raw* const pre_base = reinterpret_cast<const bf16raw*>(pre_res ? ep.R : ep.dgelu_in);
         const long pre_ld = pre_res ? ep.ldr : ep.ld_dgelu;
         const TileMap rm = make_tile_map(ep.rmap, tile_m0);
@@ -772,7 +804,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // row-vector lane needs, and 64 adds per tile instead of 128); same fp32 add, same result
       float bcol[2] = {0.f, 0.f};
       if (ep.bias) {
-        if constexpr (CONT) {                      // landed in the staging slice during K tile 0 (see above)
+        if constexpr (CF) {                        // landed in the staging slice during K tile 0 (see above)
           asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(bcol[0]), "=&v"(bcol[1]) : "v"(bias_rd) : "memory");
         } else {
@@ -784,7 +816,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         }
       }
       float sc[8][2];
-      if constexpr (HAS_SC && CONT) {              // landed in the staging slice during K tile 0: row r of the block at word 128 + r
+      if constexpr (HAS_SC && CF) {                // landed in the staging slice during K tile 0: row r of the block at word 128 + r
         const unsigned sc_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 512 + (lane >> 3) * 4);
         asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:32\n\tds_read_b32 %2, %16 offset:64\n\t"
                      "ds_read_b32 %3, %16 offset:96\n\tds_read_b32 %4, %16 offset:128\n\tds_read_b32 %5, %16 offset:160\n\t"
@@ -797,7 +829,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
                        "=&v"(sc[6][0]), "=&v"(sc[6][1]), "=&v"(sc[7][0]), "=&v"(sc[7][1])
                      : "v"(sc_rd) : "memory");
       }
-      if constexpr (HAS_SC && !CONT) {
+      if constexpr (HAS_SC && !CF) {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -810,7 +842,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
             sc[p][u] = ep.row_scale[split ? (ml - ep.split_row) : (int)q1 * ep.rs_m1 + (ml - (int)q2 * ep.rs_d2) * ep.rs_m2];
           }
       }
-      if constexpr (!CONT) {
+      if constexpr (!CF) {
         if (more && tid == 0) pending = atomicAdd(my_ctr, 1);
         // one wait for all of it; the empty asm statements make the loaded registers "used" here, so that hipcc's own
         // wait for them lands before the prologue's DMA requests and not (as vmcnt(0)) behind them
@@ -825,6 +857,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         if constexpr (!HAS_PRE) {
           if (more) { set_tile(t, 0); m0 = m0s; n0 = n0s; prologue(); }   // ring is free: the next tile's first 7 regions land under the passes
         }
+        if constexpr (PF) {
+          if (more) set_tile(t, (long)nk * (PP_BK * 2));   // the passes below request its K tiles 0 and 1 as stream positions nk, nk + 1
+        }
       }
       stamp(5);
       const TileMap cm = make_tile_map(ep.cmap, tile_m0);
@@ -834,6 +869,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       const unsigned stg_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) +
                                                                     ((lane >> 3) * PP_STG_LD + (lane & 7) * 8) * 4);
       const unsigned pre_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(pre_lds) + lane * 16);
+      // residual-block flow: pass p reads this wave's 2 KB of ring region p (buffer pa for p < 4, the other one after)
+      const unsigned pf_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(lds + wave * 1024) + lane * 16);
+      const int pa = (nk & 1) ^ par;
 #define PP_EPI2(p_, mi_, half_)                                                                         \
       {                                                                                                 \
         const int col = lane & 31, rhalf = (lane >> 5) * 4;                                             \
@@ -845,14 +883,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         __builtin_amdgcn_wave_barrier();                                                                \
         f32x4 s00, s01, s10, s11;                                                                       \
         u32x4 pre[2];                                                                                   \
-        if constexpr (HAS_PRE)                                                                          \
+        if constexpr (HAS_PRE) {                                                                        \
+          const unsigned prd__ = PF ? pf_rd + (unsigned)((((p_) < 4 ? pa : pa ^ 1) * PP_BUF + ((p_) & 3) * PP_REGION) * 2) \
+                                    : pre_rd + 2 * (p_) * 1024;                                         \
           asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\t"                       \
                        "ds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %6 offset:2064\n\t"         \
-                       "ds_read_b128 %4, %7 offset:%8\n\tds_read_b128 %5, %7 offset:%9\n\t"             \
+                       "ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:1024\n\t"                     \
                        "s_waitcnt lgkmcnt(0)"                                                           \
                        : "=&v"(s00), "=&v"(s01), "=&v"(s10), "=&v"(s11), "=&v"(pre[0]), "=&v"(pre[1])   \
-                       : "v"(stg_rd), "v"(pre_rd), "n"(2 * (p_) * 1024), "n"((2 * (p_) + 1) * 1024) : "memory"); \
-        else                                                                                            \
+                       : "v"(stg_rd), "v"(prd__) : "memory");                                           \
+        } else                                                                                            \
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"                       \
                        "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:2064\n\t"         \
                        "s_waitcnt lgkmcnt(0)"                                                           \
@@ -903,28 +943,34 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
             else store8(reinterpret_cast<bf16raw*>(ep.C) + tile_map_row(cm, ep.cmap, m) * ep.ldc + en, v[u]); \
           }                                                                                             \
         }                                                                                               \
+        if constexpr (PF) {                        /* region p_ is read: it takes the next tile's operands */ \
+          if ((p_) < 7 && more) issue((p_) & 3, nk + ((p_) >> 2));                                      \
+        }                                                                                               \
       }
       PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
       PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
 #undef PP_EPI2
       stamp(6);
-      if constexpr (HAS_PRE) {
+      if constexpr (HAS_PRE && !PF) {
         __builtin_amdgcn_s_barrier();               // every wave has read its residual block: the ring may be refilled
         if (more) { set_tile(t, 0); m0 = m0s; n0 = n0s; prologue(); }
       }
       stamp(7);
       ++trace_tile;
       if (!more) break;
-      if constexpr (CONT) {                         // the next tile's K tiles 0 and 1 are already in the ring
+      if constexpr (CONT) {                         // the next tile's K tiles 0 and 1 are in the ring / on their way
         abase += (long)nk * (PP_BK * 2); bbase += (long)nk * (PP_BK * 2);
         m0 = m0s; n0 = n0s;
         par ^= nk & 1;
-        t = t_next; t_next = t_nn;
+        if constexpr (CF) { t = t_next; t_next = t_nn; }
       }
     }
   }
   check_out();
 #undef PP_KTILE
+#undef PP_ISS_COND
+#undef PP_ISS_ALWAYS
+#undef PP_ISS_PRE
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_MMA
@@ -948,7 +994,7 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   if (cg < 1) cg = 1;
   hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
                      (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, cg,
-                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, cfg.pp_touch, ep);
+                     (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, ep);
   return check_launch("gemm_nt_pp");
 }
 
@@ -963,10 +1009,19 @@ static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st
   // offsets assume)
   const bool cont = cfg.pp_cont != 0 && (d->amap.grp <= 0 || d->amap.grp >= 256);
   if (d->act) return cont ? launch_pp_t<true, PRE_NONE, false, true, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, true, false>(d, ep, st, cfg);
-  if (d->dgelu_in)
-    return d->dgelu_kind == 1 ? launch_pp_t<true, PRE_MUL, false, false, false>(d, ep, st, cfg)
-                              : launch_pp_t<true, PRE_DGELU, false, false, false>(d, ep, st, cfg);
-  if (d->R) return sc ? launch_pp_t<true, PRE_RES, true, false, false>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, false, false, false>(d, ep, st, cfg);
+  if (d->dgelu_in) {
+    if (d->dgelu_kind == 1)
+      return cont && 256L * d->ld_dgelu * 2 < (1L << 31) ? launch_pp_t<true, PRE_MUL, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_MUL, false, false, false>(d, ep, st, cfg);
+    return launch_pp_t<true, PRE_DGELU, false, false, false>(d, ep, st, cfg);
+  }
+  if (d->R) {
+    // residual-block flow: no periodic residual, a row map with at most one group boundary per tile, 32-bit offsets
+    const bool pf = cont && d->r_period <= 0 && (d->rmap.grp <= 0 || d->rmap.grp >= 256) && d->rmap.skip >= 0 &&
+                    (256L + (d->rmap.skip > 0 ? d->rmap.skip : 0)) * d->ldr * 2 < (1L << 31);
+    if (!pf) return sc ? launch_pp_t<true, PRE_RES, true, false, false>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, false, false, false>(d, ep, st, cfg);
+    if (sc) return cont ? launch_pp_t<true, PRE_RES, true, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, true, false, false>(d, ep, st, cfg);
+    return cont ? launch_pp_t<true, PRE_RES, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, false, false, false>(d, ep, st, cfg);
+  }
   if (sc) return cont ? launch_pp_t<true, PRE_NONE, true, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, true, false, false>(d, ep, st, cfg);
   return cont ? launch_pp_t<true, PRE_NONE, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, false, false>(d, ep, st, cfg);
 }

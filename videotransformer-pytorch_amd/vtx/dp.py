@@ -47,6 +47,7 @@ class GradBuckets:
         if cur:
             self._close(cur)
         self._hooks = []
+        self._fired = set()                     # id() of the parameters whose gradient has arrived since zero()
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -62,11 +63,16 @@ class GradBuckets:
         self.buckets.append(dict(params=plist, flat=flat, pending=len(plist), handle=None, comm=None))
 
     def _make_hook(self, bi):
-        def hook(_p):
+        def hook(p):
             b = self.buckets[bi]
-            if b['pending'] <= 0:
-                raise RuntimeError('GradBuckets: a gradient arrived for a bucket whose all-reduce was already '
-                                   'launched -- call zero() before every backward (one backward per step)')
+            if id(p) in self._fired:
+                # direct gradients: the kernels' own call (vtx.functions._fire) came first; this torch version also
+                # runs a parameter's post-accumulate hooks when the Function returned None for it -- count once
+                if self.direct:
+                    return
+                raise RuntimeError('GradBuckets: a second gradient arrived for a parameter whose bucket was already '
+                                   'counted -- call zero() before every backward (one backward per step)')
+            self._fired.add(id(p))
             b['pending'] -= 1
             if b['pending'] == 0:
                 self._launch(b)
@@ -93,6 +99,7 @@ class GradBuckets:
             b['handle'] = None
             b['comm'] = None
         self._launched = []
+        self._fired = set()
 
     def finish(self):
         """Wait for every bucket's all-reduce; afterwards param.grad holds the mean gradient."""

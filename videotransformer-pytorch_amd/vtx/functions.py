@@ -54,8 +54,9 @@ def clear_weight_cache():
 # Functions below used to zero-fill the LayerNorm gradients they accumulate into): ~370 five-microsecond launches
 # per TimeSformer-B step.  With direct gradients on, the weight-gradient GEMM's reduction, its fused bias
 # column sums and the LayerNorm backward accumulate straight into ``param.grad`` (same fp32 `+=`), the Function
-# returns None for that parameter and calls the parameter's post-accumulate-grad hooks itself (the
-# data-parallel bucket hooks of vtx.dp).  Opt-in (vtx.dp.GradBuckets(..., direct=True) turns it on): it needs
+# returns None for that parameter and calls the parameter's post-accumulate-grad hooks itself, right behind the
+# kernel launch (the data-parallel bucket hooks of vtx.dp; torch 2.10 runs those hooks once more when it sees the
+# None, so hooks must count a parameter once per backward -- GradBuckets does).  Opt-in (vtx.dp.GradBuckets(..., direct=True) turns it on): it needs
 # pre-allocated contiguous fp32 ``.grad`` buffers, and only ``loss.backward()`` sees these gradients --
 # ``torch.autograd.grad`` and tensor hooks on the parameters do not.
 _direct = False
