@@ -485,6 +485,39 @@ def test_attention_contig(dtype, S, L):
     check(f'attn bwd {dtype} S={S} L={L}', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
 
 
+@pytest.mark.parametrize('S,L,H', [(401, 8, 12), (77, 9, 12), (50, 8, 5), (9, 4, 20)])
+def test_attention_short_sequences_workgroup_layouts(S, L, H, vtx_opts):
+    """Short-sequence (temporal) attention: one head and four row tiles per workgroup (attn_hw_* = 0) or n heads of one
+    row tile per workgroup -- same arithmetic per (tile, head): bit-identical outputs, log-sum-exp and gradients, for
+    head counts that do and do not divide into the groups, ragged last tiles, and against the float64 reference."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG
+    dtype = torch.bfloat16
+    hd = 64
+    D = H * hd
+    qkv = rnd(S, L, 3 * D, seed=L) * 1.5
+    do = rnd(S, L, D, seed=L + 1)
+    qq = q(qkv, dtype).requires_grad_(True)
+    ref, _ = _attn_ref(qq, H)
+    ref.backward(q(do, dtype))
+    qd, dd = dev(qkv, dtype), dev(do, dtype)
+    res = []
+    for n in ('0', '3', '16'):
+        vtx_opts('attn_hw_fwd', n)
+        vtx_opts('attn_hw_bwd', n)
+        o = torch.full((S, L, D), float('nan'), dtype=dtype, device=DEV)
+        lse = torch.full((S * H * L,), float('nan'), device=DEV)
+        ops.attn_fwd(qd, o, lse, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        dqkv = torch.full((S, L, 3 * D), float('nan'), dtype=dtype, device=DEV)
+        ops.attn_bwd(qd, o, lse, dd, dqkv, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        res.append((o, lse, dqkv))
+    check(f'attn fwd S={S} L={L} H={H}', res[0][0].float().cpu(), ref.detach(), TOL[dtype])
+    check(f'attn bwd S={S} L={L} H={H}', res[0][2].float().cpu(), qq.grad, 2 * TOL[dtype])
+    for r in res[1:]:
+        for a, b_ in zip(r, res[0]):
+            assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,T,P', [(2, 4, 9), (2, 3, 36), (1, 2, 196)])
 def test_attention_space_mode(dtype, B, T, P):

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
 // HBM-bound: forward moves 4 and backward 8 row-blocks of [rows][64] per head.
 // =====================================================================================
 constexpr int SM_WAVE_LDS_FWD = 32 * 64 * 2;                   // V tile
-constexpr int SM_WAVE_LDS_BWD = 3 * 32 * 64 * 2 + 2 * 32 * 4;   // K, Q, dO tiles + lse + delta
+constexpr int SM_WAVE_LDS_BWD = 2 * 32 * 64 * 2 + 2 * 32 * 4;   // tile A (K, then Q), tile B (dO) + lse + delta
 
 __device__ inline void put_tile(bf16raw* lds, const bf16x8 (&f)[4], int lane) {
   const int row = lane & 31;
@@ -462,12 +462,16 @@ __device__ inline void load_frags(bf16x8 (&f)[4], const bf16raw* base, long ld, 
   }
 }
 
-__global__ __launch_bounds__(MA_THREADS) void attn_fwd_small_kernel(AttnP p, int ntiles, const bf16raw* __restrict__ qkv,
+// HW (heads in the workgroup): wave w of a workgroup works on head w of ONE row tile, so that the workgroup as a whole
+// reads the tile's rows contiguously (32 x 3 H x 128 B) at one moment -- instead of one 128-B line out of every
+// 4.6 KB row per workgroup, with the other heads' lines of the same rows requested by other CUs at other times.
+template <bool HW>
+__global__ __launch_bounds__(HW ? 1024 : MA_THREADS) void attn_fwd_small_kernel(AttnP p, int ntiles, const bf16raw* __restrict__ qkv,
                                                                     bf16raw* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wave, h = blockIdx.y, D = p.H * 64;
-  if (tile >= ntiles) return;
+  const int tile = HW ? blockIdx.x : blockIdx.x * 4 + wave, h = HW ? wave + blockIdx.y * (blockDim.x >> 6) : blockIdx.y, D = p.H * 64;
+  if (tile >= ntiles || h >= p.H) return;
   bf16raw* Vs = reinterpret_cast<bf16raw*>(sm_raw + wave * SM_WAVE_LDS_FWD);
   const int L = p.L, G = 32 / L, used = G * L;
   const long row0 = (long)tile * used, total = (long)p.S * L;
@@ -512,26 +516,31 @@ __global__ __launch_bounds__(MA_THREADS) void attn_fwd_small_kernel(AttnP p, int
     for (int n2 = 0; n2 < 2; ++n2)
       acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
   }
-  if (valid) {
-    store_rows_direct(out + (row0 + i) * p.ld_out + h * 64, acc, 1.0f / l, lane);
-    if (lane < 32) {
-      const long sq = (row0 + i) / L;
-      lse[(sq * p.H + h) * L + (row0 + i - sq * L)] = m * LN2 + __logf(l);
-    }
+  // whole 128-B rows through the (now idle) V tile: the direct store writes 8-byte pieces of 32 different rows per
+  // instruction, and the vector memory pipeline handles those one line at a time
+  store_rows_T(Vs, acc, valid ? 1.0f / l : 0.f, lane, [&](int r) -> bf16raw* {
+    return (r < used && row0 + r < total) ? out + (row0 + r) * p.ld_out + h * 64 : nullptr;
+  });
+  if (valid && lane < 32) {
+    const long sq = (row0 + i) / L;
+    lse[(sq * p.H + h) * L + (row0 + i - sq * L)] = m * LN2 + __logf(l);
   }
 }
 
-__global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int ntiles, const bf16raw* __restrict__ qkv,
+template <bool HW>
+__global__ __launch_bounds__(HW ? 1024 : MA_THREADS) void attn_bwd_small_kernel(AttnP p, int ntiles, const bf16raw* __restrict__ qkv,
                                                                     const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
                                                                     const float* __restrict__ lse, bf16raw* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wave, h = blockIdx.y, D = p.H * 64;
-  if (tile >= ntiles) return;
+  const int tile = HW ? blockIdx.x : blockIdx.x * 4 + wave, h = HW ? wave + blockIdx.y * (blockDim.x >> 6) : blockIdx.y, D = p.H * 64;
+  if (tile >= ntiles || h >= p.H) return;
+  // two wave-private tiles: A holds K for phase 1 (and stages dQ), then Q for phase 2 (and stages dK); B holds dO
+  // (and stages dV) -- 8.25 KB per wave instead of 12.25 KB: LDS is what bounds the waves per CU of this kernel
   char* wl = sm_raw + wave * SM_WAVE_LDS_BWD;
   bf16raw* Ks = reinterpret_cast<bf16raw*>(wl);
-  bf16raw* Qs = Ks + 32 * 64;
-  bf16raw* Os = Qs + 32 * 64;
+  bf16raw* Qs = Ks;
+  bf16raw* Os = Ks + 32 * 64;
   float* Ls = reinterpret_cast<float*>(Os + 32 * 64);
   float* Ds = Ls + 32;
   const int L = p.L, G = 32 / L, used = G * L;
@@ -557,7 +566,6 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int
     l2 = lse[(sq * p.H + h) * L + (row0 + i - sq * L)] * LOG2E;
   }
   put_tile(Ks, kf, lane);
-  put_tile(Qs, qf, lane);
   put_tile(Os, df, lane);
   if (lane < 32) { Ls[i] = l2; Ds[i] = dl; }
   const float c2 = p.scale * LOG2E;
@@ -591,10 +599,15 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int
       for (int n2 = 0; n2 < 2; ++n2)
         acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Ks, 16 * s2, n2 * 32, lane), db, acc[n2], 0, 0, 0);
     }
-    if (valid) store_rows_direct(dqkv + (row0 + i) * p.ld_dqkv + h * 64, acc, 1.0f, lane);
+    // K tile: its last reader was the MFMA chain above
+    store_rows_T(Ks, acc, 1.0f, lane, [&](int r) -> bf16raw* {
+      return (r < used && row0 + r < total) ? dqkv + (row0 + r) * p.ld_dqkv + h * 64 : nullptr;
+    });
   }
   // ---- phase 2: lanes = keys.  dV^T = dO^T P, dK^T = Q^T dS
   {
+    put_tile(Qs, qf, lane);                        // tile A is free again: store_rows_T above ends with a wave-level sync
+    wave_lds_sync();
     f32x16 st, dp;
     zero16(st);
     zero16(dp);
@@ -632,11 +645,11 @@ __global__ __launch_bounds__(MA_THREADS) void attn_bwd_small_kernel(AttnP p, int
         dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qs, 16 * s2, n2 * 32, lane), db, dk[n2], 0, 0, 0);
       }
     }
-    if (valid) {
-      bf16raw* base = dqkv + (row0 + i) * p.ld_dqkv;
-      store_rows_direct(base + D + h * 64, dk, 1.0f, lane);
-      store_rows_direct(base + 2 * D + h * 64, dv, 1.0f, lane);
-    }
+    auto dst = [&](int r, int col) -> bf16raw* {
+      return (r < used && row0 + r < total) ? dqkv + (row0 + r) * p.ld_dqkv + col + h * 64 : nullptr;
+    };
+    store_rows_T(Qs, dk, 1.0f, lane, [&](int r) -> bf16raw* { return dst(r, D); });
+    store_rows_T(Os, dv, 1.0f, lane, [&](int r) -> bf16raw* { return dst(r, 2 * D); });
   }
 }
 
@@ -647,19 +660,40 @@ bool attn_mfma_eligible(int dtype, int L, int hd) {
 bool attn_small_eligible(int dtype, int mode, int L, int hd) {
   return dtype == VTX_BF16 && hd == 64 && mode == VTX_ATTN_CONTIG && L >= 1 && L <= 32;
 }
+// heads per workgroup in the HW variants: option value n > 0, capped at 16 waves (1024 threads) and at H
+static int hw_waves(int n, int H) { n = n < H ? n : H; return n < 16 ? n : 16; }
+
 int attn_fwd_small_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
   const int G = 32 / p.L;
   const int ntiles = (p.S + G - 1) / G;
-  hipLaunchKernelGGL(attn_fwd_small_kernel, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_FWD, st, p, ntiles,
-                     (const bf16raw*)qkv, (bf16raw*)out, lse);
+  if (options().attn_hw_fwd > 0) {
+    const int w = hw_waves(options().attn_hw_fwd, p.H);
+    hipLaunchKernelGGL(attn_fwd_small_kernel<true>, dim3(ntiles, (p.H + w - 1) / w), dim3(64 * w), w * SM_WAVE_LDS_FWD, st, p, ntiles,
+                       (const bf16raw*)qkv, (bf16raw*)out, lse);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_small_kernel<false>, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_FWD, st, p, ntiles,
+                       (const bf16raw*)qkv, (bf16raw*)out, lse);
+  }
   return check_launch("attn_fwd_small");
 }
 int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
                           hipStream_t st) {
   const int G = 32 / p.L;
   const int ntiles = (p.S + G - 1) / G;
-  hipLaunchKernelGGL(attn_bwd_small_kernel, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_BWD, st, p, ntiles,
-                     (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv);
+  if (options().attn_hw_bwd > 0) {
+    const int w = hw_waves(options().attn_hw_bwd, p.H);
+    const size_t lds = (size_t)w * SM_WAVE_LDS_BWD;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_small_kernel<true>, dim3(ntiles, (p.H + w - 1) / w), dim3(64 * w), lds, st, p, ntiles,
+                       (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_small_kernel<false>, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_BWD, st, p, ntiles,
+                       (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv);
+  }
   return check_launch("attn_bwd_small");
 }
 

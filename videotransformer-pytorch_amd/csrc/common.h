@@ -150,6 +150,8 @@ struct Options {
   int gemm_nodma = 0;        // VTX_GEMM_NODMA: register-staged GEMM kernels (no LDS-DMA)
   int tn_safe = 0;           // VTX_TN_SAFE: bounds-checked TN loader (diagnostic)
   int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
+  int attn_hw_fwd = 16;      // VTX_ATTN_HW_FWD / _BWD: short-sequence attention with n heads of a row tile in one workgroup
+  int attn_hw_bwd = 0;       //   (0: one head per workgroup, four row tiles)
   int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
   int pp_cg = 0;             // VTX_GEMM_PP_CG: column tiles per group (0: from K)
   int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing); 2 / 3 = diagnostics: no stores / no staging
