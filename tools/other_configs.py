@@ -23,35 +23,73 @@ import video_transformer as V
 DEV = torch.device('cuda', 0)
 
 
-def vivit(batch=32, steps=8, warmup=3):
+def train(name, model, batch, frames, flops_per_clip, steps=6, warmup=2, recompute=False):
+    """fwd + cross-entropy + bwd + fused SGD-nesterov exactly as bench.py does it (gradient buckets with direct
+    parameter gradients), bf16 path, synthetic clips resident in HBM."""
+    from vtx import dp, optim
     vtx.set_precision('bf16')
+    vtx.set_recompute(recompute)
     torch.manual_seed(0)
-    m = V.ViViT(num_frames=16).to(DEV).train()
+    torch.cuda.reset_peak_memory_stats()
+    m = model.to(DEV).train()
     head = T.ClassificationHead(400, m.embed_dims).to(DEV).train()
     params = list(m.parameters()) + list(head.parameters())
-    opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, nesterov=True)
-    x = torch.randn(batch, 16, 3, 224, 224, device=DEV)
+    buckets = dp.GradBuckets(params, direct=True)
+    opt = optim.FusedSGD(buckets, lr=1e-4, momentum=0.9, nesterov=True)
+    x = torch.randn(batch, frames, 3, 224, 224, device=DEV)
     y = torch.randint(0, 400, (batch,), device=DEV)
 
     def step():
-        for p in params:
-            p.grad = None
+        buckets.zero()
         loss = torch.nn.functional.cross_entropy(head(m(x)), y)
         loss.backward()
+        buckets.finish()
         opt.step()
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    flops = 0.850e12                      # ViViT-B fact_encoder T=16 fwd+bwd per clip
-    print(json.dumps({'config': 'ViViT-B fact_encoder, Conv3d tubelet 2, 16x3x224x224, bf16, fwd+CE+bwd+SGD',
-                      'clips_per_gpu': batch, 'clips_per_s': round(batch / dt, 2), 'ms_per_step': round(dt * 1e3, 2),
-                      'model_tflops': round(batch / dt * flops / 1e12, 1),
-                      'mfma_frac': round(batch / dt * flops / 1e12 / 2500.0, 4)}), flush=True)
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        peak0 = torch.cuda.max_memory_allocated()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = {'config': name, 'clips_per_gpu': batch, 'clips_per_s': round(batch / dt, 2), 'ms_per_step': round(dt * 1e3, 2),
+               'recompute': recompute, 'peak_GB': round(max(peak0, torch.cuda.max_memory_allocated()) / 2 ** 30, 1)}
+        if flops_per_clip:
+            res['model_tflops'] = round(batch / dt * flops_per_clip / 1e12, 1)
+            res['mfma_frac'] = round(batch / dt * flops_per_clip / 1e12 / 2500.0, 4)
+        print(json.dumps(res), flush=True)
+    finally:
+        buckets.remove()
+        vtx.set_recompute(False)
+        del m, head, params, opt, x
+        torch.cuda.empty_cache()
+
+
+def vivit(batch=32):
+    # SURVEY.md 8(d): ViViT-B fact_encoder T=16 fwd+bwd per clip
+    train('ViViT-B fact_encoder, Conv3d tubelet 2, 16x3x224x224, bf16, fwd+CE+bwd+SGD (BASELINE cfg 2)',
+          V.ViViT(num_frames=16), batch, 16, 0.850e12)
+
+
+def timesformer_b16(batch=48):
+    train('TimeSformer-B divided_space_time, 16x3x224x224, bf16, fwd+CE+bwd+SGD', V.TimeSformer(num_frames=16), batch, 16, 2.352e12)
+
+
+def timesformer_l96(batch=4):
+    """BASELINE cfg 4: TimeSformer-L (D 1024, 16 heads, 24 layers), 96 frames: 18 817 tokens per clip.  Per-block
+    recompute keeps one block's activations (2.1 GB per clip) instead of 24.  FLOPs per clip fwd+bwd (recompute not
+    counted): 6 * tokens * 12 D^2 * 24 layers for the Linears + attention cores."""
+    tokens, D, layers = 196 * 96 + 1, 1024, 24
+    lin = 6.0 * tokens * (13 * D * D) * layers            # qkv 3 + proj 1 + temporal qkv 3 + proj 1 + tfc 1 + FFN 8 = 17 D^2? see below
+    # per layer Linears: temporal qkv (3 D^2) + proj (D^2) + temporal_fc (D^2) + spatial qkv (3 D^2) + proj (D^2) + FFN (8 D^2) = 17 D^2
+    lin = 6.0 * tokens * (17 * D * D) * layers
+    attn = 3.0 * layers * (4.0 * tokens * 96 * D + 4.0 * tokens * 197 * D)     # fwd 4 L hd per token and head, x3 for fwd+bwd
+    train('TimeSformer-L divided_space_time (D 1024, 24 layers), 96x3x224x224, bf16, fwd+CE+bwd+SGD, per-block recompute (BASELINE cfg 4)',
+          V.TimeSformer(num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=24), batch, 96,
+          lin + attn, steps=3, warmup=1, recompute=True)
 
 
 def hog(frames_n=256, iters=20):
@@ -87,5 +125,12 @@ def hog(frames_n=256, iters=20):
 
 
 if __name__ == '__main__':
-    hog()
-    vivit()
+    which = sys.argv[1:] or ['hog', 'vivit', 'tsf16', 'tsfl96']
+    if 'hog' in which:
+        hog()
+    if 'vivit' in which:
+        vivit()
+    if 'tsf16' in which:
+        timesformer_b16()
+    if 'tsfl96' in which:
+        timesformer_l96()
