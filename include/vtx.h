@@ -199,6 +199,16 @@ int vtx_reduce_rows(int in_dtype, int nj, int ni, int D, const void* in, long ld
 int vtx_gelu_grad_mul(int dtype, size_t n, const void* dy, const void* h, void* out, void* stream);
 /* Weight staging: W fp32 [R,C] -> Wc (dtype, [R,C], optional) and WcT (dtype, [C,R], optional). */
 int vtx_cast_transpose(int dtype, int R, int C, const float* W, void* Wc, void* WcT, void* stream);
+/* The same for a whole table of weights in ONE launch (what the step after an optimizer update needs: ~86 matrices
+ * of TimeSformer-B).  tab / tile_start are DEVICE arrays: tile_start[i] = number of 64x64 tiles of tensors 0..i-1
+ * (n_tensors + 1 entries, tiles of tensor i = ceil(rows/64) * ceil(cols/64)), n_tiles = tile_start[n_tensors]. */
+typedef struct {
+  const float* src;   /* [rows, cols] fp32 */
+  void* dst_c;        /* [rows, cols] dtype, or NULL */
+  void* dst_t;        /* [cols, rows] dtype, or NULL */
+  int rows, cols;
+} vtx_ct_tensor;
+int vtx_mt_cast_transpose(int dtype, const vtx_ct_tensor* tab, const int* tile_start, int n_tensors, int n_tiles, void* stream);
 /* dst (dtype) = src (fp32), n elements; and the reverse. */
 int vtx_cast_from_f32(int dtype, size_t n, const float* src, void* dst, void* stream);
 int vtx_cast_to_f32(int dtype, size_t n, const void* src, float* dst, void* stream);

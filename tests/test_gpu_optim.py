@@ -90,3 +90,32 @@ def test_build_optimizer_groups_like_the_reference():
     # time_embed is 3-D and not among the reference's no-decay keywords: it IS decayed (optimizer.py:51-58)
     assert 'patch_embed.projection.weight' in g1 and all(n.endswith('weight') or n == 'time_embed' for n in g1)
     assert len(g0) + len(g1) == len(names)
+
+
+def test_restaged_weights_after_fused_step_match_a_fresh_cast():
+    """The fused optimizers refresh the staged bf16 / fp32 W and W^T copies of the weights they have just updated in
+    one multi-tensor launch (vtx.functions.restage_weights): bit-identical to the per-weight staging, for shapes
+    that take the vector path and shapes that do not, and the next forward uses the updated weights."""
+    import vtx
+    from vtx import functions, ops, optim
+    dev = 'cuda:0'
+    torch.manual_seed(0)
+    shapes = [(768, 768), (2304, 768), (96, 200), (130, 77), (64, 64), (8, 3072)]
+    params = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    for dtype in (torch.bfloat16, torch.float32):
+        functions.clear_weight_cache()
+        staged = [functions.weights(p, dtype, True) for p in params]
+        opt = optim.FusedSGD(params, lr=0.1, momentum=0.9, nesterov=True)
+        for p in params:
+            p.grad = torch.randn_like(p)
+        before = [p.detach().clone() for p in params]
+        opt.step()
+        torch.cuda.synchronize()
+        for p, b, (wc, wt) in zip(params, before, staged):
+            assert not torch.equal(p.detach(), b)
+            wc2, wt2 = functions.weights(p, dtype, True)
+            assert wc2 is wc or dtype == torch.float32, 'the staged copy must have been refreshed in place (cache hit)'
+            assert wt2 is wt
+            rc, rt = ops.cast_transpose(p.detach(), dtype)
+            assert torch.equal(wc2, rc) and torch.equal(wt2, rt), (tuple(p.shape), dtype)
+    functions.clear_weight_cache()

@@ -39,11 +39,18 @@ template <> struct ET<float> {
   static constexpr int VEC = 4;               // elements per 16-byte vector
   __device__ static inline float ld(const float* p) { return *p; }
   __device__ static inline void st(float* p, float v) { *p = v; }
+  __device__ static inline void st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 template <> struct ET<bf16raw> {
   static constexpr int VEC = 8;
   __device__ static inline float ld(const bf16raw* p) { return bf2f(*p); }
   __device__ static inline void st(bf16raw* p, float v) { *p = f2bf(v); }
+  __device__ static inline void st4(bf16raw* p, const float (&v)[4]) {       // 8-byte aligned
+    uint2 r;
+    r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+  }
 };
 
 // 8 consecutive elements <-> 8 floats (bf16: one 16-B access; f32: two).

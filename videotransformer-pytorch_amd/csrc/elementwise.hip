@@ -31,6 +31,67 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(int R, int C, const
   }
 }
 
+// ---- the same over a table of matrices: block b -> (tensor, 64x64 tile) by binary search in the tile prefix sums.
+// 16-byte loads and 8-byte stores where the shape allows (rows, cols multiples of 4), element-wise otherwise.
+template <typename T>
+__global__ __launch_bounds__(256) void mt_cast_transpose_kernel(const vtx_ct_tensor* __restrict__ tab, const int* __restrict__ tile_start,
+                                                                int n_tensors) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n_tensors;                  // tile_start[lo] <= b < tile_start[hi]
+  const int b = blockIdx.x;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= b) lo = mid; else hi = mid;
+  }
+  const vtx_ct_tensor t = tab[lo];
+  const int R = t.rows, C = t.cols;
+  const int l = b - tile_start[lo], tiles_c = (C + 63) >> 6;
+  const int r0 = (l / tiles_c) * 64, c0 = (l % tiles_c) * 64;
+  T* Wc = reinterpret_cast<T*>(t.dst_c);
+  T* WcT = reinterpret_cast<T*>(t.dst_t);
+  const bool vec = (R % 4 == 0) && (C % 4 == 0);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 x 16: four columns x (rows ty, ty+16, ...)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = ty + 16 * i, r = r0 + rr, c = c0 + 4 * tx;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      if (vec && c < C) {
+        const float4 a = *reinterpret_cast<const float4*>(t.src + (long)r * C + c);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        if (Wc) ET<T>::st4(Wc + (long)r * C + c, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < C) {
+            v[j] = t.src[(long)r * C + c + j];
+            if (Wc) ET<T>::st(Wc + (long)r * C + c + j, v[j]);
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rr][4 * tx + j] = v[j];
+  }
+  if (!WcT) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = ty + 16 * i, c = c0 + cc, r = r0 + 4 * tx;      // four consecutive rows of column c
+    if (c < C) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = tile[4 * tx + j][cc];
+      if (vec && r < R) {
+        ET<T>::st4(WcT + (long)c * R + r, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r + j < R) ET<T>::st(WcT + (long)c * R + r + j, v[j]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void cast_from_f32_kernel(size_t n, const float* __restrict__ src, T* __restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -313,6 +374,18 @@ extern "C" int vtx_cast_transpose(int dtype, int R, int C, const float* W, void*
              hipLaunchKernelGGL(cast_transpose_kernel<bf16raw>, grid, block, 0, st, R, C, W, (bf16raw*)Wc, (bf16raw*)WcT),
              "cast_transpose");
   return check_launch("cast_transpose");
+}
+
+extern "C" int vtx_mt_cast_transpose(int dtype, const vtx_ct_tensor* tab, const int* tile_start, int n_tensors, int n_tiles,
+                                     void* stream) {
+  VTX_REQUIRE(tab && tile_start && n_tensors > 0 && n_tiles >= 0, VTX_EINVAL, "mt_cast_transpose: bad arguments");
+  if (n_tiles == 0) return VTX_OK;
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(mt_cast_transpose_kernel<float>, dim3(n_tiles), dim3(256), 0, st, tab, tile_start, n_tensors),
+             hipLaunchKernelGGL(mt_cast_transpose_kernel<bf16raw>, dim3(n_tiles), dim3(256), 0, st, tab, tile_start, n_tensors),
+             "mt_cast_transpose");
+  return check_launch("mt_cast_transpose");
 }
 
 extern "C" int vtx_cast_from_f32(int dtype, size_t n, const float* src, void* dst, void* stream) {

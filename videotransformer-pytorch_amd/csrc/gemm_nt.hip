@@ -47,17 +47,19 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_kernel(
     const int row = lr + 32 * it;
     int ma = m0 + row; if (ma >= M) ma = M - 1;
     int nb = n0 + row; if (nb >= N) nb = N - 1;
-    ap[it] = A + map_row(amap, ma) * lda + lc * 8;
-    bp[it] = B + (long)nb * ldb + lc * 8;
+    ap[it] = A + map_row(amap, ma) * lda;
+    bp[it] = B + (long)nb * ldb;
     lds_off[it] = row * BK16 + ((lc ^ ((row >> 1) & 7)) << 3);
   }
   uint4 ra[4], rb[4];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  // chunks beyond K read the row's first chunk instead (always valid: K >= 8) and are zeroed.  (They used to read
+  // chunk lc of K tile 0, which lies beyond the row -- and, in the last row, beyond the tensor -- when K < 64.)
 #define GLOAD16(k0_)                                                                  \
   {                                                                                   \
     const int k0__ = (k0_);                                                           \
     const bool ok = (k0__ + lc * 8) < K;                                              \
-    const int ko__ = ok ? k0__ : 0; /* always-valid address; zeroed below */          \
+    const int ko__ = ok ? k0__ + lc * 8 : 0;                                          \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                \
       ra[it] = *reinterpret_cast<const uint4*>(ap[it] + ko__);                        \
       rb[it] = *reinterpret_cast<const uint4*>(bp[it] + ko__);                        \
@@ -1052,16 +1054,17 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_f32_kernel(
     const int row = lr + 64 * it;
     int ma = m0 + row; if (ma >= M) ma = M - 1;
     int nb = n0 + row; if (nb >= N) nb = N - 1;
-    ap[it] = A + map_row(amap, ma) * lda + lc * 4;
-    bp[it] = B + (long)nb * ldb + lc * 4;
+    ap[it] = A + map_row(amap, ma) * lda;
+    bp[it] = B + (long)nb * ldb;
     lds_off[it] = row * LD32 + lc * 4;
   }
   float4 ra[2], rb[2];
+  // chunks beyond K read the row's first chunk (always valid) and are zeroed
 #define GLOAD32(k0_)                                                                          \
   {                                                                                           \
     const int k0__ = (k0_);                                                                   \
     const bool ok = (k0__ + lc * 4) < K;                                                      \
-    const int ko__ = ok ? k0__ : 0;                                                           \
+    const int ko__ = ok ? k0__ + lc * 4 : 0;                                                  \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                        \
       ra[it] = *reinterpret_cast<const float4*>(ap[it] + ko__);                               \
       rb[it] = *reinterpret_cast<const float4*>(bp[it] + ko__);                               \

@@ -51,6 +51,10 @@ class GemmTnDesc(C.Structure):
     ]
 
 
+class CtTensor(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst_c', C.c_void_p), ('dst_t', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int)]
+
+
 class MtTensor(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('s1', C.c_void_p), ('s2', C.c_void_p), ('n', C.c_long),
                 ('lr', C.c_float), ('wd', C.c_float)]
@@ -112,6 +116,7 @@ SIGNATURES = {
     'vtx_reduce_rows': (ci, [ci, ci, ci, ci, vp, cl, cl, cl, cl, vp, cl, cf, ci, vp]),
     'vtx_gelu_grad_mul': (ci, [ci, sz, vp, vp, vp, vp]),
     'vtx_cast_transpose': (ci, [ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_mt_cast_transpose': (ci, [ci, vp, vp, ci, ci, vp]),
     'vtx_cast_from_f32': (ci, [ci, sz, vp, vp, vp]),
     'vtx_cast_to_f32': (ci, [ci, sz, vp, vp, vp]),
     'vtx_patch_rows': (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, cl, ci, vp]),

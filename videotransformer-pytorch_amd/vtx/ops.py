@@ -313,6 +313,28 @@ def cast_transpose(W, dtype, want_c=True, want_t=True):
     return Wc, WcT
 
 
+def ct_table(entries, device):
+    """Device table for mt_cast_transpose: entries = [(W fp32 [R,C] contiguous, Wc or None, WcT or None), ...].
+    Returns (table tensor, tile prefix sums tensor, total tiles)."""
+    tab = (_lib.CtTensor * len(entries))()
+    starts = [0]
+    for i, (W, wc, wt) in enumerate(entries):
+        need_cuda(W)
+        if not W.is_contiguous() or W.dtype != torch.float32:
+            raise ValueError('ct_table: contiguous float32 matrices expected')
+        R, Cc = W.shape
+        tab[i].src, tab[i].dst_c, tab[i].dst_t = W.data_ptr(), ptr(wc), ptr(wt)
+        tab[i].rows, tab[i].cols = R, Cc
+        starts.append(starts[-1] + ((R + 63) // 64) * ((Cc + 63) // 64))
+    tab_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
+    starts_dev = torch.tensor(starts, dtype=torch.int32).to(device)
+    return tab_dev, starts_dev, starts[-1]
+
+
+def mt_cast_transpose(dtype, tab_dev, starts_dev, n_tensors, n_tiles):
+    call('vtx_mt_cast_transpose', _DT[dtype], ptr(tab_dev), ptr(starts_dev), int(n_tensors), int(n_tiles), stream())
+
+
 def cast_from_f32(src, dtype):
     need_cuda(src)
     if dtype == torch.float32:

@@ -104,6 +104,9 @@ class _FusedBase(torch.optim.Optimizer):
         self._n_steps += 1
         self._launch(clip)
         self._bump_versions()
+        # the staged bf16 W / W^T copies of the updated weights: one launch now instead of one per weight in the next forward
+        from . import functions
+        functions.restage_weights([p for g in self.param_groups for p in g['params'] if p.grad is not None and p.ndim >= 2])
         return loss
 
     def _bump_versions(self):
