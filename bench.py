@@ -135,7 +135,7 @@ def pmc_traffic_per_launch(B, args):
         try:
             kb, rows = 0.0, 0.0
             for line in open(os.path.join(here, 'profiles', name)):
-                if 'gemm_nt_bf16_pp_kernel' in line:       # one line per template instantiation: pool them
+                if 'nt_bf16_pp_kernel' in line:            # one line per template instantiation (names are cut on the left): pool them
                     f = dict(kv.split('=') for kv in line.split() if '=' in kv)
                     kb += float(f['total'])
                     rows += float(f['rows'])
