@@ -92,6 +92,38 @@ __device__ inline bf16x8 frag_cols(const bf16raw* lds, int row0, int col0, int l
   return u.v;
 }
 
+// The same two readers with their per-lane part precomputed.  For a row0 that is a multiple of 16 the swizzle term only
+// depends on the lane, so a fragment address is (lane constant) + row0 * 128 B: the kernels keep the lane constants in
+// registers (FragOff) and the compiler turns row0 into an immediate / one scalar add -- the generic readers above cost
+// 3 (rows) to 6 (columns) vector instructions of index arithmetic per LDS read, in kernels bound by vector-ALU issue.
+struct FragOff {
+  int rows[4];        // frag_rows: element offset of (row = lane&31, ks)
+  int cols[2][2];     // frag_cols: element offset of (n2, half = rows r / r + 8), col0 = n2 * 32
+};
+__device__ inline FragOff make_frag_off(int lane) {
+  FragOff f;
+  const int row = lane & 31;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f.rows[ks] = row * 64 + (((ks * 2 + (lane >> 5)) ^ sw_of(row)) << 3);
+  const int r = 4 * (lane >> 5) + ((lane & 15) >> 2);
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2) {
+    const int c = n2 * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    f.cols[n2][0] = sw_off(r, c);
+    f.cols[n2][1] = sw_off(r + 8, c);
+  }
+  return f;
+}
+__device__ inline bf16x8 frag_rows_o(const bf16raw* lds, int row0, int ks, const FragOff& f) {     // row0 % 32 == 0
+  return *reinterpret_cast<const bf16x8*>(lds + row0 * 64 + f.rows[ks]);
+}
+__device__ inline bf16x8 frag_cols_o(const bf16raw* lds, int row0, int n2, const FragOff& f) {     // row0 % 16 == 0
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + row0 * 64 + f.cols[n2][0]));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds + row0 * 64 + f.cols[n2][1]));
+  return u.v;
+}
+
 // Row-wise operand fragment straight from global memory (rows beyond nvalid read as zero).
 template <typename RowFn>
 __device__ inline bf16x8 frag_global(const bf16raw* base, long ld, int col0, int row, int nvalid, int ks, int lane, RowFn rowfn) {
@@ -193,6 +225,8 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
   __syncthreads();
   const float c2 = p.scale * LOG2E;
   const int ragged = (p.L & 31) ? nt - 1 : -1;     // the key tile that holds padded keys
+  const FragOff fo = make_frag_off(lane);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int qt = wave; qt < nt; qt += 4) {
     bf16x8 qn[4];                                  // next query tile's fragments, in flight during this one
 #pragma unroll
@@ -202,14 +236,14 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
     zero16(acc[1]);
     float m = -1e30f, l = 0.f;                     // running max of the RAW scores (scale > 0)
     for (int kb = 0; kb < nt; kb += MA_KB) {
-      f32x16 st[MA_KB];
+      f32x16 st[MA_KB];                            // (tiles beyond nt stay undefined: every use below is guarded)
 #pragma unroll
       for (int t = 0; t < MA_KB; ++t) {
-        zero16(st[t]);
         if (kb + t < nt) {
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, (kb + t) * 32, 0, fo), qf[0], zero, 0, 0, 0);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, (kb + t) * 32, ks, lane), qf[ks], st[t], 0, 0, 0);
+          for (int ks = 1; ks < 4; ++ks)
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, (kb + t) * 32, ks, fo), qf[ks], st[t], 0, 0, 0);
         }
       }
       float bm = -1e30f;
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
             const bf16x8 pb = pack8(pf);
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2)
-              acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, (kb + t) * 32 + 16 * s2, n2 * 32, lane), pb, acc[n2], 0, 0, 0);
+              acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Vs, (kb + t) * 32 + 16 * s2, n2, fo), pb, acc[n2], 0, 0, 0);
           }
         }
     }
@@ -288,6 +322,8 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
   __syncthreads();
   const float c2 = p.scale * LOG2E;
   const int ragged = (p.L & 31) ? nt - 1 : -1;
+  const FragOff fo = make_frag_off(lane);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int qt = wave; qt < nt; qt += 4) {
     const int q = qt * 32 + (lane & 31);
     bf16x8 qf[4], df[4];
@@ -309,13 +345,12 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
     zero16(acc[0]);
     zero16(acc[1]);
     for (int kt = 0; kt < nt; ++kt) {
-      f32x16 st, dp;
-      zero16(st);
-      zero16(dp);
+      f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, kt * 32, 0, fo), qf[0], zero, 0, 0, 0);
+      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Vs, kt * 32, 0, fo), df[0], zero, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32, ks, lane), qf[ks], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kt * 32, ks, lane), df[ks], dp, 0, 0, 0);
+      for (int ks = 1; ks < 4; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, kt * 32, ks, fo), qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Vs, kt * 32, ks, fo), df[ks], dp, 0, 0, 0);
       }
       // dS = P (dP - delta); the softmax scale is applied once to dq at the store.  Padded keys have
       // zero K rows, so only their probability needs masking (they would otherwise poison nothing but
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
         const bf16x8 db = pack8(ds + 8 * s2);
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2)
-          acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Ks, kt * 32 + 16 * s2, n2 * 32, lane), db, acc[n2], 0, 0, 0);
+          acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Ks, kt * 32 + 16 * s2, n2, fo), db, acc[n2], 0, 0, 0);
       }
     }
     store_rows_T(stg, acc, p.scale, lane, [&](int r) -> bf16raw* {
@@ -376,6 +411,8 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   }
   __syncthreads();
   const float c2 = p.scale * LOG2E;
+  const FragOff fo = make_frag_off(lane);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int kt = wave; kt < nt; kt += 4) {
     bf16x8 kn[4], vn[4];                           // next key tile's fragments, in flight during this one
 #pragma unroll
@@ -386,13 +423,12 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
     f32x16 dk[2], dv[2];
     zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
     for (int qt = 0; qt < nt; ++qt) {
-      f32x16 st, dp;
-      zero16(st);
-      zero16(dp);
+      f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, 0, fo), kf[0], zero, 0, 0, 0);
+      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, 0, fo), vf[0], zero, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qt * 32, ks, lane), kf[ks], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Os, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+      for (int ks = 1; ks < 4; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, ks, fo), kf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, ks, fo), vf[ks], dp, 0, 0, 0);
       }
       // padded query rows: Ls = +huge -> P = 0; padded keys only feed dk/dv rows that are never stored
       float pr[16], ds[16];
@@ -416,8 +452,8 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
         const bf16x8 db = pack8(ds + 8 * s2);
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
-          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Os, qt * 32 + 16 * s2, n2 * 32, lane), pb, dv[n2], 0, 0, 0);
-          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Qs, qt * 32 + 16 * s2, n2 * 32, lane), db, dk[n2], 0, 0, 0);
+          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, qt * 32 + 16 * s2, n2, fo), pb, dv[n2], 0, 0, 0);
+          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, qt * 32 + 16 * s2, n2, fo), db, dk[n2], 0, 0, 0);
         }
       }
     }
