@@ -540,7 +540,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   // hooks inside the load sections of P1 .. P4.
   // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section): inside a load
   // section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
-#define PP_KTILE(E1_, E2_, W1_, W2_, ISS_, H1_, H2_, H3_, H4_)                                         \
+#define PP_KTILE(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_)                                         \
     {                                                                                                  \
       const int buf = (kt & 1) ^ par;                                                                  \
       const bool e1 = (E1_), e2 = (E2_);           /* K tile kt+1 / kt+2 exists in this tile */        \
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       PP_MMA(2, 1, fb1, ISS_(1, kt + 2, e2));                                                          \
       PP_BAR();                                                                                        \
       /* P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1) */                           \
-      if (w2) wait_vmcnt<8>(); else if (w1) wait_vmcnt<4>();                                           \
+      if (W4_) { if (w2) wait_vmcnt<8>(); else if (w1) wait_vmcnt<4>(); }                              \
       H4_                                                                                              \
       PP_BAR();                                                                                        \
       PP_MMA(2, 0, fb0, ISS_(2, kt + 2, e2));                                                          \
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       if (more_c) {
         // every request of every K tile is unconditional here
         for (; kt < nk; ++kt) {
-          PP_KTILE(true, true, true, true, PP_ISS_ALWAYS,
+          PP_KTILE(true, true, true, true, true, PP_ISS_ALWAYS,
                    if (kt == 0) {
                      if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(my_ctr), "v"(one) : "memory");
                      bias_dma();
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         }
       } else {
         for (; kt < nk; ++kt) {
-          PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, PP_ISS_COND, if (kt == 0) bias_dma();, , , )
+          PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, true, PP_ISS_COND, if (kt == 0) bias_dma();, , , )
         }
       }
     } else if constexpr (PF) {
@@ -724,13 +724,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           pre_piece(15, dst7 + 512);
         }
       };
-      // every slot carries two requests as in the steady state: steady-state wait counts throughout
+      // Every slot carries two requests as in the steady state: steady-state wait counts -- except P4 of the last K
+      // tile, whose steady-state wait names the regions of "K tile nk": block pieces the main loop does not need, which
+      // come from HBM with every CU asking for its 128 KB in the same few microseconds (requests return in order, so the
+      // wait would stall on them: measured +2.8 us per tile).  All operand requests precede all block requests.
       for (int kt = 0; kt < nk; ++kt) {
-        PP_KTILE(kt + 1 < nk, kt + 2 < nk, true, true, PP_ISS_PRE, , , , )
+        PP_KTILE(kt + 1 < nk, kt + 2 < nk, true, true, kt + 1 < nk, PP_ISS_PRE, , , , )
       }
     } else {
       for (int kt = 0; kt < nk; ++kt) {
-        PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, PP_ISS_COND, , , , )
+        PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, true, PP_ISS_COND, , , , )
       }
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
