@@ -280,9 +280,99 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// The same sums, four columns per lane (16-byte loads: 1 KB per wave instruction instead of 256 B) for the first `nvec`
+// columns (the weight-gradient part: no second output, no folded copies there); per column the additions are the
+// ones of the kernel above in the same order, so the result is bit-identical.  Blocks beyond the vector part run the
+// scalar code on columns [nvec, N).
+__global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const float* __restrict__ part, int nslabs, long stride,
+                                                                 long N, long nvec, int vec_blocks, float* __restrict__ out,
+                                                                 int accumulate, float scale, float* __restrict__ out2, long split,
+                                                                 int accumulate2, int fold, long fold_stride) {
+  __shared__ float red[4][64 * 4];
+  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  if ((int)blockIdx.x < vec_blocks) {
+    const long n = ((long)blockIdx.x * 64 + cx) * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (n < nvec) {
+      int s = sy;
+      for (; s + 12 < nslabs; s += 16) {
+        const float4 x0 = *reinterpret_cast<const float4*>(part + (long)s * stride + n);
+        const float4 x1 = *reinterpret_cast<const float4*>(part + (long)(s + 4) * stride + n);
+        const float4 x2 = *reinterpret_cast<const float4*>(part + (long)(s + 8) * stride + n);
+        const float4 x3 = *reinterpret_cast<const float4*>(part + (long)(s + 12) * stride + n);
+        add(a0, x0); add(a1, x1); add(a2, x2); add(a3, x3);
+      }
+      for (; s < nslabs; s += 4) add(a0, *reinterpret_cast<const float4*>(part + (long)s * stride + n));
+    }
+    float* r = &red[sy][cx * 4];
+    r[0] = (a0.x + a1.x) + (a2.x + a3.x); r[1] = (a0.y + a1.y) + (a2.y + a3.y);
+    r[2] = (a0.z + a1.z) + (a2.z + a3.z); r[3] = (a0.w + a1.w) + (a2.w + a3.w);
+    __syncthreads();
+    if (sy == 0 && n < nvec) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[j] = ((red[0][cx * 4 + j] + red[1][cx * 4 + j]) + (red[2][cx * 4 + j] + red[3][cx * 4 + j])) * scale;
+      float4* o = reinterpret_cast<float4*>(out + n);
+      if (accumulate) { const float4 c = *o; v[0] = c.x + v[0]; v[1] = c.y + v[1]; v[2] = c.z + v[2]; v[3] = c.w + v[3]; }
+      *o = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
+  // scalar part: columns nvec .. N-1 (the bias-gradient tail and any remainder)
+  const long n = nvec + (long)((int)blockIdx.x - vec_blocks) * 64 + cx;
+  const bool tail = out2 != nullptr && n >= split;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (n < N && !(tail && fold > 1)) {
+    int s = sy;
+    for (; s + 12 < nslabs; s += 16) {
+      a0 += part[(long)s * stride + n];
+      a1 += part[(long)(s + 4) * stride + n];
+      a2 += part[(long)(s + 8) * stride + n];
+      a3 += part[(long)(s + 12) * stride + n];
+    }
+    for (; s < nslabs; s += 4) a0 += part[(long)s * stride + n];
+  } else if (n < N) {
+    const int total = nslabs * fold;
+    int v = sy, s = sy / fold, f = sy - (sy / fold) * fold;
+    auto next = [&]() { v += 4; f += 4; while (f >= fold) { f -= fold; ++s; } };
+    auto at = [&]() { return v < total ? part[(long)s * stride + (long)f * fold_stride + n] : 0.f; };
+    while (v < total) {
+      const float x0 = at(); next();
+      const float x1 = at(); next();
+      const float x2 = at(); next();
+      const float x3 = at(); next();
+      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+    }
+  }
+  red[sy][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sy == 0 && n < N) {
+    const float a = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * scale;
+    if (tail) {
+      float* o = out2 + (n - split);
+      *o = accumulate2 ? *o + a : a;
+    } else {
+      out[n] = accumulate ? out[n] + a : a;
+    }
+  }
+}
+
 int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
                            int accumulate, float scale, hipStream_t st, float* out2, long split, int accumulate2,
                            int fold, long fold_stride) {
+  // vector part: columns below the second output's start (all of them without one), in whole groups of four
+  const long lim = out2 != nullptr ? (split < N ? split : N) : N;
+  const long nvec = lim & ~3L;
+  const bool vec_ok = nvec >= 4096 && stride % 4 == 0 && ((uintptr_t)part % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (vec_ok) {
+    const int vec_blocks = (int)cdiv(nvec, 256);
+    const int tail_blocks = (int)cdiv(N - nvec, 64);
+    hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3(vec_blocks + tail_blocks), dim3(256), 0, st, part, nslabs, stride, N, nvec,
+                       vec_blocks, out, accumulate, scale, out2, split, accumulate2, fold, fold_stride);
+    return check_launch("reduce_partials_v4");
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, part, nslabs,
                      stride, N, out, accumulate, scale, out2, split, accumulate2, fold, fold_stride);
   return check_launch("reduce_partials");
