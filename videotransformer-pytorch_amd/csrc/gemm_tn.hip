@@ -636,6 +636,19 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     const unsigned vo = isA ? voff_a : voff_b, vc = 2u * (unsigned)(isA ? acol_l : rc);
     const unsigned step8 = 16u * (unsigned)(isA ? lda : ldb);
     const int row = prow0 + 8 * j;
+    // Regular K tile (all 64 rows before the next row-map group and inside M -- a scalar test; all but one tile in
+    // ~24 of the spatial / temporal row maps and every tile of the identity map): scalar base + the lane's constant
+    // offset, i.e. the request is `s_mov m0` + one saddr-form DMA instruction and fits an MFMA gap.  The general
+    // form below is a dozen dependent vector instructions per piece: two of them per MMA section stretched it by a
+    // third (tools/tn_timeline.py: 500 cycles for 8 MFMAs).
+    if (crs[kind] >= TP_BK && vld[kind] >= TP_BK) {
+      // (inline asm: written with the builtin, hipcc merges this branch with the general one below and the request is
+      // again a per-lane 64-bit address built from a dozen instructions)
+      const unsigned m0v = (unsigned)(unsigned long)(tn_lds_char*)(dst + j * 512);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :: "v"(vo + j * step8), "s"(lo), "s"(m0v) : "memory", "m0");
+      return;
+    }
     const char* base = row >= crs[kind] ? hi : lo;
     const unsigned o = row < vld[kind] ? vo + j * step8 : vc;
     tn_dma16(reinterpret_cast<const bf16raw*>(base + o), dst + j * 512);
