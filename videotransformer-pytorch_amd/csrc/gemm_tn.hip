@@ -784,6 +784,12 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   // B fragment set is free one phase before it is needed: B1 is read during P1's MFMAs (into Y), the NEXT tile's B0
   // during P4's (into the registers B1 just left), so the load sections are 16 / 0 / 16 / 0 reads.  X / Y swap roles
   // every K tile (the loop is unrolled by two).
+  // Requests: an LDS-DMA piece between two MFMAs stretches the MMA section by ~60 cycles (8 bare MFMAs + partner: 320,
+  // with two pieces 450), and the MMA sections are the critical path (load sections end in a barrier wait); the two
+  // read-free load sections P2 / P4 take one region's request each (A1(kt+1), B0(kt+2): same issue order, in front of
+  // the section's counted wait), the other two stay in the MFMA gaps of P2 / P4 -- four pieces in one load section
+  // made it the longer side (750 cycles), and fragment reads moved INTO the gaps cost ~10 cycles each there (measured:
+  // all 48 in gaps 3261 us per layer against 2989).
 #define TP_KTILE(kt_, X_, Y_)                                                                            \
   {                                                                                                      \
     const int kt = (kt_);                                                                                \
@@ -803,13 +809,13 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     TP_BAR();                                                                                            \
     stamp(3);                                                                                            \
     TP_PIN_A(); TP_PIN_B(X_);                                                                            \
-    TP_MMA(0, 0, X_, if (n1) issue_piece(3, kt + 1, 0), if (n1) issue_piece(3, kt + 1, 1),              \
+    TP_MMA(0, 0, X_, , ,                                                                                 \
            TP_READ_B_Q(buf, 2, Y_, 0), TP_READ_B_Q(buf, 2, Y_, 1), TP_READ_B_Q(buf, 2, Y_, 2), TP_READ_B_Q(buf, 2, Y_, 3)); \
     stamp(15);                                                                                           \
     TP_BAR();                                                                                            \
     stamp(4);                                                                                            \
     /* P2: no reads (B1 arrived in Y_ during P1); P3 will read A1(kt) */                                 \
-    if (n1) advance(3);                                                                                  \
+    if (n1) { issue(3, kt + 1); advance(3); }        /* A1(kt+1): requested here, not between the MFMAs (see above) */ \
     tp_lgkm0();                                                                                          \
     stamp(5);                                                                                            \
     if (n1) tn_wait_vmcnt<8>(); else tn_wait_vmcnt<0>();                                                 \
@@ -836,13 +842,15 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
     TP_BAR();                                                                                            \
     stamp(10);                                                                                           \
     TP_PIN_A();                                                                                          \
-    TP_MMA(2, 1, Y_, if (n2) issue_piece(1, kt + 2, 0), if (n2) issue_piece(1, kt + 2, 1), , , , );      \
+    TP_MMA(2, 1, Y_, , , , , , );                                                                        \
     stamp(17);                                                                                           \
     TP_BAR();                                                                                            \
     stamp(11);                                                                                           \
     /* P4: no reads of its own; B0(kt+1) (published by P3's barrier) is read into Y_ during the MFMAs */ \
-    if (n2) advance(1);                                                                                  \
-    if (n2) tn_wait_vmcnt<6>();                      /* B1(kt+1) landed */                               \
+    if (n2) {                                                                                            \
+      issue(1, kt + 2); advance(1);                  /* B0(kt+2): this section has no reads, see above */ \
+      tn_wait_vmcnt<6>();                            /* B1(kt+1) landed */                               \
+    }                                                                                                    \
     stamp(12);                                                                                           \
     TP_BAR();                                                                                            \
     stamp(13);                                                                                           \
