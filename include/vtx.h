@@ -191,6 +191,17 @@ int vtx_cls_qkv_reduce(int dtype, int B, int T, int W, const void* dqkv_cls, lon
 int vtx_row_scale_copy(int dtype, int rows, int D, const void* src, long lds, vtx_rowmap smap,
                        void* dst, long ldd, vtx_rowmap dmap, const float* s,
                        int rs_d1, int rs_m1, int rs_d2, int rs_m2, void* stream);
+/* Rows of dropped DropPath groups (s[m / group_rows] == 0.0f; a group = group_rows consecutive rows m of [0, M)):
+ *   out[omap(m)] = x[xmap(m)] + bias   (out may be NULL),   zero[m] = 0   (zero may be NULL; compact [M, D] rows).
+ * Fix-up behind the merged attn.proj + temporal_fc GEMM: the reference's DropPath sits between the two Linear layers
+ * (transformer.py:268-275), so a dropped sequence leaves the block as x + temporal_fc.bias. */
+int vtx_dropped_rows_fix(int dtype, long M, int D, int group_rows, const float* s, const void* x, long ldx,
+                         vtx_rowmap xmap, const float* bias, void* out, long ldo, vtx_rowmap omap, void* zero,
+                         long ldz, void* stream);
+/* part[w, :] (fp32, [nparts, D]) = column sums of src[smap(m), :] over the rows of the dropped groups inside the w-th of
+ * nparts runs of consecutive groups; fold the rows of `part` with vtx_reduce_rows (fixed order, no atomics). */
+int vtx_dropped_rows_colsum(int dtype, long M, int D, int group_rows, const float* s, const void* src, long lds,
+                            vtx_rowmap smap, float* part, int nparts, void* stream);
 /* out[j,:] (+)= scale * sum_{i<ni} in[base + i*si + j*sj, :]   (fp32 out).  in_dtype: VTX_F32/BF16. */
 int vtx_reduce_rows(int in_dtype, int nj, int ni, int D, const void* in, long ld, long base,
                     long si, long sj, float* out, long ldo, float scale, int accumulate, void* stream);

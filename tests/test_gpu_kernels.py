@@ -618,6 +618,42 @@ def test_glue_ops(dtype):
     assert dst[:, 1:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_dropped_rows_kernels(dtype):
+    """vtx_dropped_rows_fix / _colsum: the fix-ups behind the merged attn.proj + temporal_fc GEMM act on exactly the
+    rows of the groups whose DropPath scale is 0 (token rows through the row map, cls rows untouched)."""
+    from vtx import ops
+    B, T, P, D = 3, 4, 7, 200
+    N = P * T
+    M = B * N
+    tm = ops.tokmap(N)
+    g = torch.Generator().manual_seed(5)
+    s = (torch.rand(M // T, generator=g) > 0.3).float() * 1.25
+    assert 0 < (s == 0).sum() < s.numel()
+    x, out0, o0, bias = rnd(B, 1 + N, D, seed=1), rnd(B, 1 + N, D, seed=2), rnd(M, D, seed=3), rnd(D, seed=4)
+    out, o = dev(out0, dtype), dev(o0, dtype)
+    ops.dropped_rows_fix(dev(s), M, D, T, x=dev(x, dtype), xmap=tm, bias=dev(bias), out=out, omap=tm, zero=o)
+    drop = (s == 0).repeat_interleave(T).reshape(B, N)
+    ref_out = q(out0, dtype).clone()
+    ref_out[:, 1:][drop] = (q(x, dtype)[:, 1:] + bias.double())[drop]
+    ref_o = q(o0, dtype).clone()
+    ref_o[drop.reshape(M)] = 0
+    check(f'dropped_rows_fix out {dtype}', out.float().cpu(), ref_out, TOL[dtype])
+    assert torch.equal(out[:, 0].cpu(), out0.to(dtype)[:, 0])                     # cls rows untouched
+    assert torch.equal(out[:, 1:].cpu()[~drop], out0.to(dtype)[:, 1:][~drop])     # kept rows untouched
+    assert torch.equal(o.float().cpu().double(), ref_o)
+    for nparts in (1, 5, 32):
+        part = ops.dropped_rows_colsum(dev(x, dtype), dev(s), M, D, T, smap=tm, nparts=nparts)
+        assert tuple(part.shape) == (nparts, D)
+        check(f'dropped_rows_colsum {dtype} nparts={nparts}', part.sum(0).cpu(), q(x, dtype)[:, 1:][drop].sum(0), 1e-4)
+    # ragged last group, nothing dropped / everything dropped
+    M2 = M - 2
+    for sv in (torch.ones(M // T), torch.zeros(M // T)):
+        part = ops.dropped_rows_colsum(dev(o0, dtype), dev(sv), M2, D, T, nparts=3)
+        ref = q(o0, dtype)[:M2].sum(0) if sv[0] == 0 else torch.zeros(D, dtype=torch.float64)
+        check(f'dropped_rows_colsum ragged {dtype}', part.sum(0).cpu(), ref, 1e-4)
+
+
 @pytest.mark.parametrize('ts', [1, 2])
 def test_patch_rows_bit_exact(ts):
     """Patch / tubelet indexing must be bit-exact (fp32 path: pure data movement)."""

@@ -210,6 +210,36 @@ def test_block_recompute_gives_identical_gradients():
         assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
+@pytest.mark.parametrize('prec,tol,gtol', [('fp32', 2e-5, 2e-4), ('bf16', TOL_BF16, TOL_BF16_GRAD)])
+def test_merged_temporal_fc_matches_the_two_linear_layers(prec, tol, gtol):
+    """attn.proj + DropPath + temporal_fc as one GEMM with the product weight (vtx.functions.TimeAttnFn, the default)
+    against the two GEMMs of the reference (transformer.py:268-275), same DropPath draws, drop rate high enough that
+    dropped and kept sequences both occur: fp32 agrees to re-association error, bf16 within the parity bars (and the
+    goldens above bound each path against the reference separately)."""
+    import vtx
+    import transformer as T_
+    import video_transformer as V
+    from vtx import functions
+    vtx.set_precision(prec)
+    res = []
+    try:
+        for merged in (True, False):
+            functions.set_merge_temporal_fc(merged)
+            m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
+            for mod in m.modules():
+                if isinstance(mod, T_.DropPath):
+                    mod.dropout_p = 0.4
+            y, grads = _train_step(m, synth.synth_clip(3, 4, 3, 64, 64, seed=2), 11, 128)
+            res.append((y.detach().float().cpu(), {k: v.float().cpu() for k, v in grads.items()}))
+    finally:
+        functions.set_merge_temporal_fc(True)
+    check(f'merged temporal_fc {prec} out', res[0][0], res[1][0], tol)
+    assert set(res[0][1]) == set(res[1][1])
+    for k in res[1][1]:
+        e = relerr(res[0][1][k], res[1][1][k])
+        assert e <= gtol, f'{prec} {k}: {e:.3e} > {gtol}'
+
+
 def test_direct_parameter_gradients_match_autograd_accumulation():
     """vtx.dp.GradBuckets(direct=True): the weight-gradient reductions, bias column sums and LayerNorm backward
     accumulate straight into the bucket views and fire the bucket hooks themselves (vtx.functions.set_direct_grads).

@@ -327,6 +327,75 @@ static inline int grid_for(long work, int block, int cap = 4096) {
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
+
+// ---- rows of dropped DropPath groups (s[m / group_rows] == 0) --------------------------------------
+// The merged attn.proj + temporal_fc GEMM (vtx/functions.py TimeAttnFn) computes s * (acc + b') + x; for a dropped
+// group the reference's value is x + b_tfc (transformer.py:268-275: the DropPath sits BETWEEN the two Linear layers),
+// and the group's rows must not reach the merged weight gradient.  One wave per group; a kept group's wave exits.
+template <typename T>
+__global__ __launch_bounds__(256) void dropped_rows_fix_kernel(long M, int D, int group_rows, const float* __restrict__ s,
+                                                               const T* __restrict__ x, long ldx, vtx_rowmap xmap,
+                                                               const float* __restrict__ bias, T* __restrict__ out, long ldo,
+                                                               vtx_rowmap omap, T* __restrict__ zero, long ldz) {
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long m0 = g * group_rows;
+  if (m0 >= M || s[g] != 0.f) return;
+  const int lane = threadIdx.x & 63;
+  const float z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < group_rows && m0 + r < M; ++r) {
+    const long m = m0 + r;
+    for (int c = lane * 8; c < D; c += 512) {
+      if (out) {
+        float v[8], b[8];
+        load8(x + map_row(xmap, m) * ldx + c, v);
+        load8(bias + c, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
+        store8(out + map_row(omap, m) * ldo + c, v);
+      }
+      if (zero) store8(zero + m * ldz + c, z8);
+    }
+  }
+}
+
+// part[w, :] = sum of src[smap(m), :] over the rows m of the dropped groups among block w's run of consecutive groups
+// (fixed partition, fixed order: deterministic; the caller folds the nparts rows with vtx_reduce_rows).
+// grid = (column chunks of 128, nparts); 256 threads = 32 column lanes (x4 columns) x 8 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void dropped_rows_colsum_kernel(long M, int D, int group_rows, const float* __restrict__ s,
+                                                                  const T* __restrict__ src, long lds_, vtx_rowmap smap,
+                                                                  float* __restrict__ part, long n_groups) {
+  __shared__ float red[8][128 + 4];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 128 + cl * 4;
+  const long per = (n_groups + gridDim.y - 1) / gridDim.y;
+  const long g0 = (long)blockIdx.y * per, g1 = g0 + per < n_groups ? g0 + per : n_groups;
+  float a[4] = {0, 0, 0, 0};
+  for (long g = g0; g < g1; ++g) {
+    if (s[g] != 0.f) continue;                     // uniform over the block
+    if (c < D)
+      for (int r = rl; r < group_rows; r += 8) {
+        const long m = g * group_rows + r;
+        if (m >= M) break;
+        const T* p = src + map_row(smap, m) * lds_ + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += ET<T>::ld(p + e);
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = a[e];
+  __syncthreads();
+  if (rl == 0 && c < D) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += red[i][cl * 4 + e];
+      part[(long)blockIdx.y * D + c + e] = t;
+    }
+  }
+}
+
 }  // namespace vtx
 
 using namespace vtx;
@@ -457,6 +526,36 @@ extern "C" int vtx_row_scale_copy(int dtype, int rows, int D, const void* src, l
              hipLaunchKernelGGL(row_scale_copy_kernel<bf16raw>, grid, block, 0, st, rows, D, (const bf16raw*)src, lds, smap, (bf16raw*)dst, ldd, dmap, s, rs_d1, rs_m1, rs_d2, rs_m2),
              "row_scale_copy");
   return check_launch("row_scale_copy");
+}
+
+extern "C" int vtx_dropped_rows_fix(int dtype, long M, int D, int group_rows, const float* s, const void* x, long ldx,
+                                    vtx_rowmap xmap, const float* bias, void* out, long ldo, vtx_rowmap omap, void* zero,
+                                    long ldz, void* stream) {
+  VTX_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && group_rows > 0 && s, VTX_EINVAL, "dropped_rows_fix: bad arguments");
+  VTX_REQUIRE(out || zero, VTX_EINVAL, "dropped_rows_fix: nothing to do");
+  VTX_REQUIRE(!out || (x && bias), VTX_EINVAL, "dropped_rows_fix: out needs x and bias");
+  const long groups = (M + group_rows - 1) / group_rows;
+  dim3 grid((unsigned)((groups + 3) / 4)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dropped_rows_fix_kernel<float>, grid, block, 0, st, M, D, group_rows, s, (const float*)x, ldx, xmap, bias, (float*)out, ldo, omap, (float*)zero, ldz),
+             hipLaunchKernelGGL(dropped_rows_fix_kernel<bf16raw>, grid, block, 0, st, M, D, group_rows, s, (const bf16raw*)x, ldx, xmap, bias, (bf16raw*)out, ldo, omap, (bf16raw*)zero, ldz),
+             "dropped_rows_fix");
+  return check_launch("dropped_rows_fix");
+}
+
+extern "C" int vtx_dropped_rows_colsum(int dtype, long M, int D, int group_rows, const float* s, const void* src, long lds,
+                                       vtx_rowmap smap, float* part, int nparts, void* stream) {
+  VTX_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && group_rows > 0 && s && src && part && nparts > 0 && nparts <= 65535, VTX_EINVAL,
+              "dropped_rows_colsum: bad arguments");
+  const long groups = (M + group_rows - 1) / group_rows;
+  dim3 grid((unsigned)((D + 127) / 128), (unsigned)nparts), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dropped_rows_colsum_kernel<float>, grid, block, 0, st, M, D, group_rows, s, (const float*)src, lds, smap, part, groups),
+             hipLaunchKernelGGL(dropped_rows_colsum_kernel<bf16raw>, grid, block, 0, st, M, D, group_rows, s, (const bf16raw*)src, lds, smap, part, groups),
+             "dropped_rows_colsum");
+  return check_launch("dropped_rows_colsum");
 }
 
 extern "C" int vtx_reduce_rows(int in_dtype, int nj, int ni, int D, const void* in, long ld, long base, long si, long sj,

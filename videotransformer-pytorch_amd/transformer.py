@@ -96,6 +96,11 @@ def _drop_scale(layer_drop, rows, ndim, device):
     return layer_drop.scale_vector(rows, ndim, device) if isinstance(layer_drop, DropPath) else None
 
 
+def _keep_scale(layer_drop):
+    """The non-zero value of scale_vector(): 1 / keep, in the same float32 arithmetic."""
+    return float(np.float32(1.0) / np.float32(1 - layer_drop.dropout_p))
+
+
 def _build_layer_drop(layer_drop):
     # the reference pops both keys from the caller's dict (transformer.py:221-222)
     p = layer_drop.pop('dropout_p')
@@ -241,7 +246,8 @@ class DividedTemporalAttentionWithPreNorm(_DividedBase):
         s = _drop_scale(self.layer_drop, b * p, 3, x.device)
         return F_.TimeAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                         self.attn.proj.weight, self.attn.proj.bias, self.temporal_fc.weight,
-                        self.temporal_fc.bias, t, self.num_heads, s, self.norm.eps)
+                        self.temporal_fc.bias, t, self.num_heads, s, self.norm.eps,
+                        _keep_scale(self.layer_drop) if s is not None else None)
 
 
 class DividedSpatialAttentionWithPreNorm(_DividedBase):

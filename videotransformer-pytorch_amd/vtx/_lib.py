@@ -112,6 +112,8 @@ SIGNATURES = {
     'vtx_cls_mean_fwd': (ci, [ci, ci, ci, ci, vp, cl, vp, vp, cl, cl, vp]),
     'vtx_space_grad_prep': (ci, [ci, ci, ci, ci, ci, vp, cl, vp, vp, cl, vp]),
     'vtx_cls_qkv_reduce': (ci, [ci, ci, ci, ci, vp, cl, vp, cl, cl, vp]),
+    'vtx_dropped_rows_fix': (ci, [ci, cl, ci, ci, vp, vp, cl, RowMap, vp, vp, cl, RowMap, vp, cl, vp]),
+    'vtx_dropped_rows_colsum': (ci, [ci, cl, ci, ci, vp, vp, cl, RowMap, vp, ci, vp]),
     'vtx_row_scale_copy': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, ci, ci, ci, ci, vp]),
     'vtx_reduce_rows': (ci, [ci, ci, ci, ci, vp, cl, cl, cl, cl, vp, cl, cf, ci, vp]),
     'vtx_gelu_grad_mul': (ci, [ci, sz, vp, vp, vp, vp]),

@@ -78,10 +78,44 @@ def restage_weights(params):
             _wcache[(id(p), dtype)] = (hit[0], (p._version, p.data_ptr(), p.device), hit[2], hit[3])
 
 
+_mcache = {}
+_merge_tfc = True
+
+
+def set_merge_temporal_fc(on):
+    """TimeAttnFn: run attn.proj and temporal_fc as ONE GEMM with the product weight (default) or as the two GEMMs
+    of the reference (transformer.py:268-275)."""
+    global _merge_tfc
+    _merge_tfc = bool(on)
+
+
+def merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtype, need_t):
+    """attn.proj followed by temporal_fc is linear in the attention output (only a per-sequence DropPath scale sits
+    between them): W_c = W_tfc W_proj, b_c = W_tfc b_proj, in fp32 from the fp32 parameters (two plain library
+    products of 768^3 -- the only rocBLAS calls of the path), staged like any other weight.  Returns
+    (W_c, W_c^T, b_c); cached while the four parameters are unchanged (same validity rule as ``weights``)."""
+    ps = (proj_w, proj_b, tfc_w, tfc_b)
+    key = (id(proj_w), id(tfc_w), dtype)
+    stamp = tuple((p._version, p.data_ptr(), p.device) for p in ps)
+    hit = _mcache.get(key)
+    if hit is not None and all(r() is p for r, p in zip(hit[0], ps)) and hit[1] == stamp and (hit[3] is not None or not need_t):
+        return hit[2], hit[3], hit[4]
+    with torch.no_grad(), torch.autocast('cuda', enabled=False):   # fp32 products also inside an autocast region
+        wc32 = torch.mm(tfc_w.detach().float(), proj_w.detach().float())
+        bc = torch.mv(tfc_w.detach().float(), proj_b.detach().float())
+    wc, wt = ops.cast_transpose(wc32, dtype, want_c=True, want_t=need_t)
+    if len(_mcache) > 1024:
+        for k in [k for k, v in _mcache.items() if any(r() is None for r in v[0])]:
+            del _mcache[k]
+    _mcache[key] = (tuple(weakref.ref(p) for p in ps), stamp, wc, wt, bc)
+    return wc, wt, bc
+
+
 def clear_weight_cache():
     """Drop every staged compute-dtype weight copy (call after out-of-band parameter updates that the cache
     validity check cannot see)."""
     _wcache.clear()
+    _mcache.clear()
     _restage_tables.clear()
 
 
@@ -156,11 +190,22 @@ def _chk(x):
 
 # ---------------------------------------------------------------------------------
 class TimeAttnFn(torch.autograd.Function):
-    """DividedTemporalAttentionWithPreNorm.forward, use_cls_token=False
-    (reference transformer.py:234-282): proj and temporal_fc are two GEMMs with DropPath between them."""
+    """DividedTemporalAttentionWithPreNorm.forward, use_cls_token=False (reference transformer.py:234-282).
+
+    attn.proj and temporal_fc have only the per-sequence DropPath scale s between them, so
+        out = x + b_tfc + s * (o W_c^T + b_c),      W_c = W_tfc W_proj,  b_c = W_tfc b_proj
+    is ONE GEMM (``merged_proj``; three launches of 150k x 768 x 768 less per layer and step than the two Linear
+    layers: forward, input gradient, weight gradient).  With s in {0, c}: the epilogue computes
+    s * (acc + b_c + b_tfc / c) + x, and the rows of dropped sequences (s = 0) are set to x + b_tfc by
+    vtx_dropped_rows_fix, which also zeroes their rows of o -- they then drop out of the weight-gradient product, and
+    the attention backward never needs them (their do is 0).  Backward, with G = c * dout^T o (kept rows):
+        dW_tfc = G W_proj^T + u b_proj^T,  dW_proj = W_tfc^T G,  db_proj = W_tfc^T u,  db_tfc = colsum(dout),
+        u = c * (colsum(dout) - colsum over dropped rows of dout).
+    ``set_merge_temporal_fc(False)`` runs the two GEMMs of the reference instead."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec, eps=1e-5):
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec, eps=1e-5,
+                keep_scale=None):
         x = _chk(x)
         B, N1, D = x.shape
         N = N1 - 1
@@ -168,11 +213,13 @@ class TimeAttnFn(torch.autograd.Function):
         hd = D // heads
         tm = ops.tokmap(N)
         dtp = x.dtype
+        need_t = any(ctx.needs_input_grad)
+        merged = _merge_tfc and (scale_vec is None or keep_scale is not None)
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
         ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
-        wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
+        wq, wqT = weights(qkv_w, dtp, need_t)
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
         o = _empty((M, D), x)
@@ -180,25 +227,35 @@ class TimeAttnFn(torch.autograd.Function):
         lse = _empty((S * heads * T,), x, torch.float32)
         scale = hd ** -0.5
         ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, T, heads, hd, scale)
-        wp, wpT = weights(proj_w, dtp, any(ctx.needs_input_grad))
-        a = _empty((M, D), x)
-        ops.gemm_nt(o, wp, a, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(T, 1, 1, 0))
-        wt, wtT = weights(tfc_w, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
-        ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=x, rmap=tm)
+        if merged:
+            wc, wcT, bc = merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtp, need_t)
+            c = 1.0 if scale_vec is None else float(keep_scale)
+            bias = torch.add(bc, tfc_b.detach().float(), alpha=1.0 / c)
+            ops.gemm_nt(o, wc, out, M, D, D, cmap=tm, bias=bias, R=x, rmap=tm, row_scale=scale_vec, rs=(T, 1, 1, 0))
+            if scale_vec is not None:
+                ops.dropped_rows_fix(scale_vec, M, D, T, x=x, xmap=tm, bias=tfc_b.detach(), out=out, omap=tm, zero=o)
+            a = x.new_empty(0)
+            wts = [t for t in (wqT, wcT) if t is not None]
+        else:
+            wp, wpT = weights(proj_w, dtp, need_t)
+            a = _empty((M, D), x)
+            ops.gemm_nt(o, wp, a, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(T, 1, 1, 0))
+            wt, wtT = weights(tfc_w, dtp, need_t)
+            ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=x, rmap=tm)
+            wts = [t for t in (wqT, wpT, wtT) if t is not None]
         ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
         ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse, a,
-                              scale_vec if scale_vec is not None else x.new_empty(0),
-                              *[t for t in (wqT, wpT, wtT) if t is not None])
-        ctx.cfg = (T, heads, scale_vec is not None)
+                              scale_vec if scale_vec is not None else x.new_empty(0), *wts)
+        ctx.cfg = (T, heads, scale_vec is not None, merged, keep_scale)
         ctx.params = (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, ln_w, mean, rstd, xn, qkv, o, lse, a, sv, wqT, wpT, wtT = ctx.saved_tensors
+        x, ln_w, mean, rstd, xn, qkv, o, lse, a, sv, wqT, *wrest = ctx.saved_tensors
         p_ln_w, p_ln_b, p_qkv_w, p_qkv_b, p_proj_w, p_proj_b, p_tfc_w, p_tfc_b = ctx.params
-        T, heads, has_scale = ctx.cfg
+        T, heads, has_scale, merged, keep_scale = ctx.cfg
         sv = sv if has_scale else None
         dout = _chk(dout)
         B, N1, D = x.shape
@@ -208,14 +265,39 @@ class TimeAttnFn(torch.autograd.Function):
         S = M // T
         tm = ops.tokmap(N)
         dtp = x.dtype
-        # temporal_fc
-        d_tfc_w, d_tfc_b = _linear_grads(p_tfc_w, p_tfc_b, dout, a, M, D, D, amap=tm)
-        da = _empty((M, D), x)
-        ops.gemm_nt(dout, wtT, da, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
-        # proj
-        d_proj_w, d_proj_b = _linear_grads(p_proj_w, p_proj_b, da, o, M, D, D)
         do = _empty((M, D), x)
-        ops.gemm_nt(da, wpT, do, M, D, D)
+        if merged:
+            wcT, = wrest
+            c = float(keep_scale) if has_scale else 1.0
+            G, cs_all = ops.gemm_tn(dout, o, M, D, D, amap=tm, want_colsum=True)
+            ops.gemm_nt(dout, wcT, do, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
+            if has_scale:
+                part = ops.dropped_rows_colsum(dout, sv, M, D, T, smap=tm)
+                u = cs_all * c
+                ops.reduce_rows(part, 1, part.shape[0], D, D, 0, 1, 0, out=u, scale=-c, accumulate=True)
+            else:
+                u = cs_all
+            pw, pb, tw = p_proj_w.detach(), p_proj_b.detach(), p_tfc_w.detach()
+            with torch.autocast('cuda', enabled=False):
+                d_tfc_w = torch.addr(torch.mm(G, pw.t()).mul_(c), u, pb)
+                d_tfc_b = cs_all
+                d_proj_w = torch.mm(tw.t(), G).mul_(c)
+                d_proj_b = torch.mv(tw.t(), u)
+            sinks = [_sink(p) for p in (p_tfc_w, p_tfc_b, p_proj_w, p_proj_b)]
+            if all(g is not None for g in sinks):      # the same `grad += new` autograd would do
+                for g, d in zip(sinks, (d_tfc_w, d_tfc_b, d_proj_w, d_proj_b)):
+                    g.add_(d)
+                _fire(p_tfc_w, p_tfc_b, p_proj_w, p_proj_b)
+                d_tfc_w = d_tfc_b = d_proj_w = d_proj_b = None
+        else:
+            wpT, wtT = wrest
+            # temporal_fc
+            d_tfc_w, d_tfc_b = _linear_grads(p_tfc_w, p_tfc_b, dout, a, M, D, D, amap=tm)
+            da = _empty((M, D), x)
+            ops.gemm_nt(dout, wtT, da, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
+            # proj
+            d_proj_w, d_proj_b = _linear_grads(p_proj_w, p_proj_b, da, o, M, D, D)
+            ops.gemm_nt(da, wpT, do, M, D, D)
         # attention core
         dqkv = _empty((M, 3 * D), x)
         ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, T, heads, hd, hd ** -0.5)
@@ -230,9 +312,10 @@ class TimeAttnFn(torch.autograd.Function):
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
         ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None, None)
 
 
+# ---------------------------------------------------------------------------------
 class SpaceAttnFn(torch.autograd.Function):
     """DividedSpatialAttentionWithPreNorm.forward, use_cls_token=True
     (reference transformer.py:336-382).  LayerNorm and the qkv / proj Linears are

@@ -288,6 +288,23 @@ def row_scale_copy(src, dst, rows, D, lds=None, smap=IDENT, ldd=None, dmap=IDENT
          D if ldd is None else ldd, dmap, ptr(s), int(rs[0]), int(rs[1]), int(rs[2]), int(rs[3]), stream())
 
 
+def dropped_rows_fix(s, M, D, group_rows, x=None, xmap=IDENT, bias=None, out=None, omap=IDENT, zero=None, ldx=None, ldo=None):
+    """Rows of the groups with s == 0: out[omap(m)] = x[xmap(m)] + bias; zero[m] = 0 (either part optional)."""
+    ref = out if out is not None else zero
+    need_cuda(ref, s)
+    call('vtx_dropped_rows_fix', dt(ref), M, D, group_rows, ptr(s), ptr(x), D if ldx is None else ldx, xmap, ptr(bias),
+         ptr(out), D if ldo is None else ldo, omap, ptr(zero), D, stream())
+
+
+def dropped_rows_colsum(src, s, M, D, group_rows, smap=IDENT, lds=None, nparts=32):
+    """[nparts, D] fp32 partial column sums of src over the rows of the groups with s == 0."""
+    need_cuda(src, s)
+    part = torch.empty((nparts, D), dtype=torch.float32, device=src.device)
+    call('vtx_dropped_rows_colsum', dt(src), M, D, group_rows, ptr(s), ptr(src), D if lds is None else lds, smap, ptr(part),
+         nparts, stream())
+    return part
+
+
 def reduce_rows(inp, nj, ni, D, ld, base, si, sj, out=None, scale=1.0, accumulate=False):
     need_cuda(inp)
     if out is None:
@@ -300,6 +317,8 @@ def reduce_rows(inp, nj, ni, D, ld, base, si, sj, out=None, scale=1.0, accumulat
 def cast_transpose(W, dtype, want_c=True, want_t=True):
     """fp32 [R,C] parameter -> (Wc [R,C], WcT [C,R]) in `dtype` (fp32: Wc is W itself)."""
     need_cuda(W)
+    if W.dtype != torch.float32:
+        raise TypeError(f'vtx: cast_transpose stages fp32 weights, got {W.dtype}')
     R, Cc = W.shape
     W = W.contiguous()
     code = _DT[dtype]
