@@ -321,6 +321,9 @@ def main():
             'clips_per_sec_per_gpu': round(value / world, 3),
             'model_tflops_per_gpu': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12, 2),
             'mfma_frac_whole_step': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12 / PEAK_BF16, 4),
+            'model_flops_note': 'model_tflops / mfma_frac_whole_step price the NOMINAL FLOPs of the reference graph (BASELINE.md '
+                                'section 3); the merged attn.proj + temporal_fc GEMM (DESIGN.md 4.4) executes 5.7 % fewer at 8 frames. '
+                                'roofline.* counts executed FLOPs only.',
             'final_loss': round(final_loss, 4),
             'roofline': {'kernel': 'gemm_nt_bf16_pp_kernel (all vtx_gemm_nt launches)' if args.precision == 'bf16' else 'gemm_nt_f32_kernel',
                          'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',

@@ -72,8 +72,8 @@ def main():
     a_cls = torch.empty(B * T, D, device=DEV, dtype=sdt)
     # ---- forward
     nt('qkv_t fwd', Mt, 3 * D, D, Mt * 3 * D * es, bias=bias[3 * D])
-    nt('proj_t fwd', Mt, D, D, Mt * D * es, bias=bias[D], row_scale=sv_t, rs=(T, 1, 1, 0))
-    nt('tfc fwd (+x)', Mt, D, D, 2 * Mt * D * ss, C=out, cmap=tm, bias=bias[D], R=x, rmap=tm)
+    # attn.proj and temporal_fc run as ONE GEMM with the product weight (vtx/functions.py TimeAttnFn)
+    nt('proj.tfc fwd (+x)', Mt, D, D, 2 * Mt * D * ss, C=out, cmap=tm, bias=bias[D], R=x, rmap=tm, row_scale=sv_t, rs=(T, 1, 1, 0))
     nt('qkv_s fwd', Ms, 3 * D, D, Ms * 3 * D * es, bias=bias[3 * D])
     nt('proj_s fwd (+x)', Mo, D, D, 2 * Mt * D * ss + B * T * D * ss, C=out, cmap=tm, bias=bias[D], row_scale=sv_s,
        rs=(N, T, T, 1), R=x, rmap=tm, split_row=B * N, Csplit=a_cls)
@@ -84,8 +84,7 @@ def main():
        R=x.view(Ms, D))
     # ---- input gradients
     dout = r(B, N + 1, D)
-    nt('tfc dgrad', Mt, D, D, Mt * D * es, A=dout, amap=tm, row_scale=sv_t, rs=(T, 1, 1, 0))
-    nt('proj_t dgrad', Mt, D, D, Mt * D * es)
+    nt('proj.tfc dgrad', Mt, D, D, Mt * D * es, A=dout, amap=tm, row_scale=sv_t, rs=(T, 1, 1, 0))
     nt('qkv_t dgrad', Mt, D, 3 * D, Mt * D * es)
     nt('proj_s dgrad', Mo, D, D, Mo * D * es)
     nt('qkv_s dgrad', Ms, D, 3 * D, Ms * D * es)
@@ -102,8 +101,7 @@ def main():
         t = timeit(lambda: ops.gemm_tn(A, Bm, M, N1, N2, out=o, want_colsum=True, **kw))
         rows.append(('TN ' + tag, M, N1, N2, t, 2.0 * M * N1 * N2, M * (N1 + N2) * es + N1 * N2 * 4))
 
-    tn('tfc wgrad', Mt, D, D, A=dout, amap=tm)
-    tn('proj_t wgrad', Mt, D, D)
+    tn('proj.tfc wgrad', Mt, D, D, A=dout, amap=tm)
     tn('qkv_t wgrad', Mt, 3 * D, D)
     tn('proj_s wgrad', Mo, D, D)
     tn('qkv_s wgrad', Ms, 3 * D, D)

@@ -366,21 +366,29 @@ __global__ __launch_bounds__(256) void dropped_rows_colsum_kernel(long M, int D,
                                                                   const T* __restrict__ src, long lds_, vtx_rowmap smap,
                                                                   float* __restrict__ part, long n_groups) {
   __shared__ float red[8][128 + 4];
+  __shared__ float flag[256];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 128 + cl * 4;
   const long per = (n_groups + gridDim.y - 1) / gridDim.y;
   const long g0 = (long)blockIdx.y * per, g1 = g0 + per < n_groups ? g0 + per : n_groups;
   float a[4] = {0, 0, 0, 0};
-  for (long g = g0; g < g1; ++g) {
-    if (s[g] != 0.f) continue;                     // uniform over the block
-    if (c < D)
-      for (int r = rl; r < group_rows; r += 8) {
-        const long m = g * group_rows + r;
-        if (m >= M) break;
-        const T* p = src + map_row(smap, m) * lds_ + c;
+  // the scales of 256 groups per coalesced load (one dependent global load per group made the scan the whole cost)
+  for (long gb = g0; gb < g1; gb += 256) {
+    __syncthreads();
+    flag[threadIdx.x] = gb + threadIdx.x < g1 ? s[gb + threadIdx.x] : 1.f;
+    __syncthreads();
+    const int n = g1 - gb < 256 ? (int)(g1 - gb) : 256;
+    for (int i = 0; i < n; ++i) {
+      if (flag[i] != 0.f) continue;                // uniform over the block
+      if (c < D)
+        for (int r = rl; r < group_rows; r += 8) {
+          const long m = (gb + i) * group_rows + r;
+          if (m >= M) break;
+          const T* p = src + map_row(smap, m) * lds_ + c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] += ET<T>::ld(p + e);
-      }
+          for (int e = 0; e < 4; ++e) a[e] += ET<T>::ld(p + e);
+        }
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = a[e];

@@ -296,7 +296,7 @@ def dropped_rows_fix(s, M, D, group_rows, x=None, xmap=IDENT, bias=None, out=Non
          ptr(out), D if ldo is None else ldo, omap, ptr(zero), D, stream())
 
 
-def dropped_rows_colsum(src, s, M, D, group_rows, smap=IDENT, lds=None, nparts=32):
+def dropped_rows_colsum(src, s, M, D, group_rows, smap=IDENT, lds=None, nparts=96):
     """[nparts, D] fp32 partial column sums of src over the rows of the groups with s == 0."""
     need_cuda(src, s)
     part = torch.empty((nparts, D), dtype=torch.float32, device=src.device)
