@@ -19,6 +19,20 @@ template <> __device__ inline void ld4<bf16raw>(const bf16raw* p, float (&v)[4])
   v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
   v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
 }
+// streaming (nontemporal) form for rows that are read once: the forward kernel has one row per wave in flight (8 waves
+// per SIMD x 1.5 KB = 48 KB per CU against a 32-KB vector L1); with plain loads it ran at 4.4 TB/s and got SLOWER with
+// more rows in flight (second row prefetched: 150 us, two rows per trip: 145 us); `nt` loads: 104.8 -> 95.6 us
+typedef unsigned ln_u32x2 __attribute__((ext_vector_type(2)));
+typedef float ln_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ inline void ld4_nt(const T* p, float (&v)[4]);
+template <> __device__ inline void ld4_nt<float>(const float* p, float (&v)[4]) {
+  ln_f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const ln_f32x4*>(p)); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ inline void ld4_nt<bf16raw>(const bf16raw* p, float (&v)[4]) {
+  ln_u32x2 r = __builtin_nontemporal_load(reinterpret_cast<const ln_u32x2*>(p));
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
 template <typename T> __device__ inline void st4(T* p, const float (&v)[4]);
 template <> __device__ inline void st4<float>(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -62,7 +76,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
       if (col < D) {
-        ld4<T>(xr + col, v[c]);
+        ld4_nt<T>(xr + col, v[c]);
         s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
       } else {
         v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
@@ -99,10 +113,10 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
 
 // raw 4-element vectors (kept packed while a prefetched row waits in registers)
 template <typename T> struct Raw4;
-template <> struct Raw4<float> { typedef float4 type; };
-template <> struct Raw4<bf16raw> { typedef uint2 type; };
-__device__ inline void unpack4(const float4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
-__device__ inline void unpack4(const uint2& r, float (&v)[4]) {
+template <> struct Raw4<float> { typedef ln_f32x4 type; };
+template <> struct Raw4<bf16raw> { typedef ln_u32x2 type; };
+__device__ inline void unpack4(const ln_f32x4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+__device__ inline void unpack4(const ln_u32x2& r, float (&v)[4]) {
   v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
   v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
 }
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && NCH <= 3) ? 3 : 1
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
       if (FULL || col < D) {
-        w.x[c] = *reinterpret_cast<const raw_t*>(xr + col);
+        w.x[c] = *reinterpret_cast<const raw_t*>(xr + col);      // (`nt` loads: +-0 here, unlike the forward kernel)
         w.dy[c] = *reinterpret_cast<const raw_t*>(dyr + col);
         if (RES) w.dr[c] = *reinterpret_cast<const raw_t*>(drr + col);
       }
