@@ -21,7 +21,9 @@ template <> __device__ inline void ld4<bf16raw>(const bf16raw* p, float (&v)[4])
 }
 // streaming (nontemporal) form for rows that are read once: the forward kernel has one row per wave in flight (8 waves
 // per SIMD x 1.5 KB = 48 KB per CU against a 32-KB vector L1); with plain loads it ran at 4.4 TB/s and got SLOWER with
-// more rows in flight (second row prefetched: 150 us, two rows per trip: 145 us); `nt` loads: 104.8 -> 95.6 us
+// more rows in flight (second row prefetched: 150 us, with `nt` 142 us; two rows per trip: 145 us); `nt` loads:
+// 104.8 -> 95.6 us.  The backward kernel (two rows per trip already): 205 -> 183 us.  NOT for the attention kernels'
+// fragment loads: those touch a 128-B line in four 32-B pieces and need the L1 to merge them (temporal forward 182 -> 275 us).
 typedef unsigned ln_u32x2 __attribute__((ext_vector_type(2)));
 typedef float ln_f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> __device__ inline void ld4_nt(const T* p, float (&v)[4]);
@@ -45,6 +47,25 @@ template <> __device__ inline void st4<bf16raw>(bf16raw* p, const float (&v)[4])
 }
 
 constexpr int LN_WAVES = 4;
+
+// raw 4-element vectors (kept packed while a prefetched row waits in registers)
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16raw> { typedef uint2 type; };
+__device__ inline float4 ld_raw_nt(const float4* p) {
+  const ln_f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const ln_f32x4*>(p));
+  return make_float4(a.x, a.y, a.z, a.w);
+}
+__device__ inline uint2 ld_raw_nt(const uint2* p) {
+  const ln_u32x2 a = __builtin_nontemporal_load(reinterpret_cast<const ln_u32x2*>(p));
+  return make_uint2(a.x, a.y);
+}
+__device__ inline void unpack4(const float4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+__device__ inline void unpack4(const uint2& r, float (&v)[4]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+
 
 template <typename T, int NCH>
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
@@ -111,16 +132,6 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
   }
 }
 
-// raw 4-element vectors (kept packed while a prefetched row waits in registers)
-template <typename T> struct Raw4;
-template <> struct Raw4<float> { typedef ln_f32x4 type; };
-template <> struct Raw4<bf16raw> { typedef ln_u32x2 type; };
-__device__ inline void unpack4(const ln_f32x4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
-__device__ inline void unpack4(const ln_u32x2& r, float (&v)[4]) {
-  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-}
-
 // Backward.  Each wave walks rows r = w, w + W, ...; per-lane column partials of
 // dgamma/dbeta stay in registers, are combined across the block's 4 waves in
 // LDS and written to part[block][2][D]; reduce_partials_kernel finishes.
@@ -160,9 +171,9 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && NCH <= 3) ? 3 : 1
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
       if (FULL || col < D) {
-        w.x[c] = *reinterpret_cast<const raw_t*>(xr + col);      // (`nt` loads: +-0 here, unlike the forward kernel)
-        w.dy[c] = *reinterpret_cast<const raw_t*>(dyr + col);
-        if (RES) w.dr[c] = *reinterpret_cast<const raw_t*>(drr + col);
+        w.x[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(xr + col));
+        w.dy[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(dyr + col));
+        if (RES) w.dr[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(drr + col));
       }
     }
   };
