@@ -79,6 +79,14 @@ __device__ inline void store8(bf16raw* p, const float (&v)[8]) {
   *reinterpret_cast<bf16x8*>(p) = o;
 }
 
+// streaming form (nontemporal): results that the launch itself never reads back
+__device__ inline void store8_nt(bf16raw* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+  __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+}
+
 // ---- row maps ---------------------------------------------------------------
 // Row indices fit 32 bits: use a 32-bit unsigned division (a 64-bit one costs ~100 instructions
 // and this sits in GEMM loaders / epilogues).

@@ -127,6 +127,19 @@ __device__ inline void dma16(const bf16raw* src, bf16raw* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Result stores of the persistent kernel are nontemporal: a result is never read back by the launch, and as ordinary
+// stores the 0.2 - 0.9 GB of it pushed the A panels out of L2 before the other column tiles of the group had re-read
+// them.  Same box, back to back: 6114 -> 5911 us per layer over the twelve NT GEMMs (qkv forward 548 -> 520, fc1
+// 959 -> 937), 692 -> 700 clips/s in the step.  (The same policy on the LayerNorm and attention outputs measured
+// -0.6 % in the step: LayerNorm stand-alone 96 -> 99 / 183 -> 195 us.)
+#define PP_ST8 store8_nt
+// the same request with the nontemporal policy (aux = 2): for blocks that are read exactly once (the epilogue's residual /
+// multiplier block), never for operands -- those are re-read out of L2 by the other column tiles
+__device__ inline void dma16_nt(const bf16raw* src, bf16raw* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_dma_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         const int lr = l + (l >= pbl ? pskip : 0);
         const char* b = pbase;
         asm volatile("" : "+s"(b));
-        dma16(reinterpret_cast<const bf16raw*>(b + ((unsigned)lr * pld2 + penc2)), dst);
+        dma16_nt(reinterpret_cast<const bf16raw*>(b + ((unsigned)lr * pld2 + penc2)), dst);
       };
       auto pre_slot = [&](int kind, int ktv) {
         const int s = (ktv - nk) * 4 + kind;
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
             if (ep.act == 2) {                     /* GELU, second output = its derivative */          \
               float gp[8];                                                                              \
               _Pragma("unroll") for (int j = 0; j < 8; ++j) gelu_erf_both(v[u][j], v[u][j], gp[j]);     \
-              if (ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, gp);           \
+              if (ok) PP_ST8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, gp);        \
             } else {                                                                                    \
               if (ep.C2 && ok) store8(reinterpret_cast<bf16raw*>(ep.C2) + (long)m * ep.ldc2 + en, v[u]); \
               _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] = gelu_erf(v[u][j]);                \
@@ -945,7 +958,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           }                                                                                             \
           if (ok) {                                                                                     \
             if (split) store8(reinterpret_cast<bf16raw*>(ep.Csplit) + (long)(m - ep.split_row) * ep.ldsplit + en, v[u]); \
-            else store8(reinterpret_cast<bf16raw*>(ep.C) + tile_map_row(cm, ep.cmap, m) * ep.ldc + en, v[u]); \
+            else PP_ST8(reinterpret_cast<bf16raw*>(ep.C) + tile_map_row(cm, ep.cmap, m) * ep.ldc + en, v[u]); \
           }                                                                                             \
         }                                                                                               \
         if constexpr (PF) {                        /* region p_ is read: it takes the next tile's operands */ \
