@@ -214,7 +214,7 @@ class TimeAttnFn(torch.autograd.Function):
         tm = ops.tokmap(N)
         dtp = x.dtype
         need_t = any(ctx.needs_input_grad)
-        merged = _merge_tfc and (scale_vec is None or keep_scale is not None)
+        merged = _merge_tfc and (scale_vec is None or keep_scale is not None) and proj_b is not None and tfc_b is not None
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
