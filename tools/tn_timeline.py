@@ -11,10 +11,10 @@ import torch
 import vtx
 from vtx import ops
 
-SEG = ['P1 issue 24 transpose reads + lgkmcnt(0)', 'P1 vmcnt wait (B1 of this tile)', 'P1 barrier', 'P1 8 MFMAs (+ A1 request) + barrier',
-       'P2 issue 8 reads + lgkmcnt(0)', 'P2 vmcnt wait (A1)', 'P2 barrier', 'P2 8 MFMAs (+ A0 request) + barrier',
-       'P3 issue 16 reads + lgkmcnt(0)', 'P3 barrier', 'P3 8 MFMAs (+ B0 request) + barrier',
-       'P4 vmcnt wait (A0, B0 of next tile)', 'P4 barrier', 'P4 8 MFMAs (+ B1 request) + barrier']
+SEG = ['P1 16 transpose reads (A0) + lgkmcnt(0)', 'P1 (stamp only)', 'P1 barrier', 'P1 8 MFMAs (+ 8 reads of B1 in the gaps) + barrier',
+       'P2 request A1(kt+1) + lgkmcnt(0)', 'P2 vmcnt wait (A1 of this tile)', 'P2 barrier', 'P2 8 MFMAs (+ A0(kt+2) request in the gaps) + barrier',
+       'P3 16 transpose reads (A1) + vmcnt wait (A0, B0 of next tile)', 'P3 barrier', 'P3 8 MFMAs + barrier',
+       'P4 request B0(kt+2) + vmcnt wait (B1 of next tile)', 'P4 barrier', 'P4 8 MFMAs (+ B1(kt+2) request, 8 reads of next B0 in the gaps) + barrier']
 a = [int(x) for x in sys.argv[1:4]] if len(sys.argv) >= 4 else [150528, 768, 3072]
 M, N1, N2 = a
 dev = 'cuda:0'
