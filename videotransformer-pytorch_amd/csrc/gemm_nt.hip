@@ -131,7 +131,8 @@ __device__ inline void dma16(const bf16raw* src, bf16raw* lds_wave_base) {
 // stores the 0.2 - 0.9 GB of it pushed the A panels out of L2 before the other column tiles of the group had re-read
 // them.  Same box, back to back: 6114 -> 5911 us per layer over the twelve NT GEMMs (qkv forward 548 -> 520, fc1
 // 959 -> 937), 692 -> 700 clips/s in the step.  (The same policy on the LayerNorm and attention outputs measured
-// -0.6 % in the step: LayerNorm stand-alone 96 -> 99 / 183 -> 195 us.)
+// -0.6 % in the step: LayerNorm stand-alone 96 -> 99 / 183 -> 195 us; restricting the policy to results wider than 2048
+// columns -- so that the 231-MB ones may stay in the memory-side cache for their consumer -- measured -0.6 % as well.)
 #define PP_ST8 store8_nt
 // the same request with the nontemporal policy (aux = 2): for blocks that are read exactly once (the epilogue's residual /
 // multiplier block), never for operands -- those are re-read out of L2 by the other column tiles
