@@ -91,8 +91,9 @@ def set_merge_temporal_fc(on):
 
 def merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtype, need_t):
     """attn.proj followed by temporal_fc is linear in the attention output (only a per-sequence DropPath scale sits
-    between them): W_c = W_tfc W_proj, b_c = W_tfc b_proj, in fp32 from the fp32 parameters (two plain library
-    products of 768^3 -- the only rocBLAS calls of the path), staged like any other weight.  Returns
+    between them): W_c = W_tfc W_proj, b_c = W_tfc b_proj, in fp32 from the fp32 parameters (plain library products,
+    weights x weights: these and the mapping of the merged weight gradient back to the two layers in
+    TimeAttnFn.backward are the only rocBLAS calls of the path), staged like any other weight.  Returns
     (W_c, W_c^T, b_c); cached while the four parameters are unchanged (same validity rule as ``weights``)."""
     ps = (proj_w, proj_b, tfc_w, tfc_b)
     key = (id(proj_w), id(tfc_w), dtype)
