@@ -322,13 +322,13 @@ __global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const float* __
     if (n < nvec) {
       int s = sy;
       for (; s + 12 < nslabs; s += 16) {
-        const float4 x0 = *reinterpret_cast<const float4*>(part + (long)s * stride + n);
-        const float4 x1 = *reinterpret_cast<const float4*>(part + (long)(s + 4) * stride + n);
-        const float4 x2 = *reinterpret_cast<const float4*>(part + (long)(s + 8) * stride + n);
-        const float4 x3 = *reinterpret_cast<const float4*>(part + (long)(s + 12) * stride + n);
+        const float4 x0 = ld_raw_nt(reinterpret_cast<const float4*>(part + (long)s * stride + n));
+        const float4 x1 = ld_raw_nt(reinterpret_cast<const float4*>(part + (long)(s + 4) * stride + n));
+        const float4 x2 = ld_raw_nt(reinterpret_cast<const float4*>(part + (long)(s + 8) * stride + n));
+        const float4 x3 = ld_raw_nt(reinterpret_cast<const float4*>(part + (long)(s + 12) * stride + n));
         add(a0, x0); add(a1, x1); add(a2, x2); add(a3, x3);
       }
-      for (; s < nslabs; s += 4) add(a0, *reinterpret_cast<const float4*>(part + (long)s * stride + n));
+      for (; s < nslabs; s += 4) add(a0, ld_raw_nt(reinterpret_cast<const float4*>(part + (long)s * stride + n)));
     }
     float* r = &red[sy][cx * 4];
     r[0] = (a0.x + a1.x) + (a2.x + a3.x); r[1] = (a0.y + a1.y) + (a2.y + a3.y);
