@@ -213,7 +213,7 @@ def main():
     import __graft_entry__ as ge
     ge.ensure_built()
     import vtx
-    from vtx import dp, ops, optim
+    from vtx import dp, ops, optim, functions as F_
     import transformer as T
     import video_transformer as V
 
@@ -247,7 +247,7 @@ def main():
     def step():
         buckets.zero()
         logits = head(model(x))
-        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss = F_.SoftmaxXentFn.apply(logits, labels)        # vtx_softmax_xent_fwd / _bwd (csrc/head.hip)
         loss.backward()
         buckets.finish()
         if opt is not None:

@@ -132,6 +132,26 @@ typedef struct {
 size_t vtx_gemm_tn_workspace(int M, int N1, int N2);
 int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream);
 
+/* Small fp32 products of weights with weights (exact-fp32 matrix instruction, fixed summation order):
+ *   C[N1,N2] (+)= alpha * sum_k A(i,k) B(k,j)  (+ u[i] v[j]),     A(i,k) = A[i*a_rs + k*a_ks], B(k,j) = B[k*b_ks + j*b_cs]
+ * (exactly one stride of each operand is 1), and optionally, from the same A tiles,
+ *   y[i] (+)= alpha_y * sum_k A(i,k) x[k] + beta_z * z[i].
+ * The merged attn.proj o temporal_fc GEMM of the divided temporal attention (transformer.py:268-275: two Linear layers
+ * with only a DropPath row scale between them) forms W_c = W_tfc W_proj, b_c = W_tfc b_proj with it and maps the merged
+ * weight gradient G back: dW_tfc = c G W_proj^T + u b_proj^T, dW_proj = c W_tfc^T G, db_proj = W_tfc^T u.
+ * N1, N2, K multiples of 4; 16-byte aligned operands. */
+typedef struct {
+  int N1, N2, K;
+  const float* A; long a_rs, a_ks;
+  const float* B; long b_ks, b_cs;
+  float alpha;
+  float* C; long ldc; int accumulate;
+  const float* u; const float* v;     /* rank-1 term, added unscaled; both or neither */
+  const float* x; float* y;           /* vector product; both or neither */
+  float alpha_y; const float* z; float beta_z; int y_accumulate;
+} vtx_wprod_desc;
+int vtx_wprod(const vtx_wprod_desc* d, void* stream);
+
 /* out[n] (+)= sum_m A[amap(m)][n]   (bias gradients). */
 size_t vtx_colsum_workspace(int M, int N);
 int vtx_colsum(int dtype, int M, int N, const void* A, long lda, vtx_rowmap amap,
@@ -335,15 +355,19 @@ int vtx_mixup_target(const long* labels, int B, int C, float on_value, float off
                      float* out, void* stream);
 /* Softmax cross-entropy on fp32 logits [B,C] with EITHER soft targets [B,C] (timm SoftTargetCrossEntropy,
  * model_trainer.py:87-88) or int64 labels (nn.CrossEntropyLoss, :91).  loss_rows[b] = sum_c -t log_softmax(x);
- * loss_mean[0] (optional) = their mean, summed in a fixed order; lse[b] saved for backward.
- * bwd: dlogits = grad_scale * grad_loss[0] * (softmax * sum_c t - t); grad_scale = 1/B for the mean, grad_loss =
- * the upstream gradient of the scalar loss ON THE DEVICE (NULL = 1). */
+ * lse[b] saved for backward.  loss_mean (optional, float[2]): [0] = mean of loss_rows over the COUNTED rows, summed in
+ * a fixed order, [1] = their number.  Every row counts, except rows whose label lies outside [0, C) -- that is
+ * nn.CrossEntropyLoss's default ignore_index = -100 (loss 0, no gradient, not in the denominator; torch raises a device
+ * assert for other out-of-range labels, here they are ignored the same way).
+ * bwd: dlogits = grad_scale * grad_loss[0] / count[0] * (softmax * sum_c t - t); grad_loss = the upstream gradient of
+ * the scalar loss ON THE DEVICE (NULL = 1); count (device, NULL = 1) = forward's loss_mean + 1 with grad_scale = 1 for
+ * the mean; or grad_scale = 1/B with count = NULL when every row counts. */
 int vtx_softmax_xent_fwd(const float* logits, const float* soft_targets, const long* labels, int B, int C, float* loss_rows,
                          float* lse, float* loss_mean, void* stream);
 int vtx_softmax_xent_bwd(const float* logits, const float* soft_targets, const long* labels, const float* lse, int B, int C,
-                         float grad_scale, const float* grad_loss, float* dlogits, void* stream);
+                         float grad_scale, const float* grad_loss, const float* count, float* dlogits, void* stream);
 /* correct[0] += number of rows whose label is among the k largest scores (torchmetrics Accuracy(top_k),
- * model_trainer.py:83-84,213-214); ties resolved like torch.topk (lower index first). */
+ * model_trainer.py:83-84,213-214); ties resolved like torch.topk (lower index first); a label outside [0, C) is never correct. */
 int vtx_topk_correct(const float* scores, const long* labels, int B, int C, int k, int* correct, void* stream);
 
 /* ------------------------------------------------- optimizer step / gradient clipping
@@ -372,6 +396,20 @@ int vtx_mt_sgd_step(const vtx_mt_tensor* tab, const int* chunk_start, int n_tens
 /* torch.optim.AdamW(betas, eps, weight_decay = tab[t].wd), step counted from 1. */
 int vtx_mt_adamw_step(const vtx_mt_tensor* tab, const int* chunk_start, int n_tensors, int n_chunks, const float* norms,
                       float clip, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------- data-parallel gradient exchange: NOT in this library
+ * SURVEY.md section 8(b2) lists vtx_dp_{init, allreduce_bucket, finalize} in the minimum export set.  They are deliberately
+ * absent: the exchange (the reference gets it from Lightning's DDP plugin, model_pretrain.py:200-204) is host-side
+ * orchestration of RCCL collectives, and this library's rules -- no allocation, no synchronisation, no state -- exclude
+ * owning communicators, bucket memory and side streams.  It lives in Python over torch.distributed (backend "nccl" = RCCL
+ * on ROCm; SURVEY.md section 7 step 8 allows exactly this): videotransformer-pytorch_amd/vtx/dp.py
+ *     init             -> torch.distributed.init_process_group (model_pretrain.single_run, bench.py)
+ *     allreduce_bucket -> GradBuckets: flat fp32 buckets in reverse layer order, one async all-reduce(mean) per bucket,
+ *                         issued from the post-accumulate hook of its last gradient (or directly behind the kernel that
+ *                         wrote it: this library's weight-gradient kernels accumulate straight into the bucket views)
+ *     finalize         -> GradBuckets.finish() (wait; fold 1/world when the backend has no AVG op)
+ * What the kernels contribute is only that they tolerate the collective's CUs (dynamic tile scheduling, grid-agnostic
+ * results) and write gradients where the collective reads them. */
 
 /* MFMA / LDS-transpose layout self-test: runs one-hot probes through the
  * instructions the GEMM kernels rely on and writes a report; returns the

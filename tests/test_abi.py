@@ -61,7 +61,7 @@ def test_struct_layouts_match_ctypes(tmp_path):
     the size and field offsets the C compiler gives include/vtx.h (compiled here as plain C)."""
     import subprocess
     from vtx import _lib
-    structs = {'vtx_rowmap': _lib.RowMap, 'vtx_gemm_desc': _lib.GemmDesc, 'vtx_gemm_tn_desc': _lib.GemmTnDesc,
+    structs = {'vtx_rowmap': _lib.RowMap, 'vtx_gemm_desc': _lib.GemmDesc, 'vtx_gemm_tn_desc': _lib.GemmTnDesc, 'vtx_wprod_desc': _lib.WprodDesc,
                'vtx_attn_desc': _lib.AttnDesc, 'vtx_attn_bwd_desc': _lib.AttnBwdDesc, 'vtx_mt_tensor': _lib.MtTensor, 'vtx_pool_desc': _lib.PoolDesc, 'vtx_xattn_desc': _lib.XAttnDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "vtx.h")}"',
              'int main(void) {']

@@ -48,6 +48,34 @@ def test_selftest():
     assert fails == 0, buf.value.decode()
 
 
+# --------------------------------------------------------------------------- weights x weights (fp32)
+@pytest.mark.parametrize('ta', [False, True])
+@pytest.mark.parametrize('tb', [False, True])
+@pytest.mark.parametrize('N1,N2,K', [(768, 768, 768), (128, 192, 96), (68, 132, 36)])
+def test_wprod(ta, tb, N1, N2, K):
+    """vtx_wprod = alpha * op(A) op(B) + u v^T (+ C), and y = alpha_y * op(A) x + beta_z * z (+ y), every transposition,
+    full and ragged tiles -- the five rocBLAS products of the merged attn.proj o temporal_fc path (reference
+    transformer.py:268-275) as three launches of this library."""
+    from vtx import ops
+    A = rnd(*((K, N1) if ta else (N1, K)), seed=1)
+    B = rnd(*((N2, K) if tb else (K, N2)), seed=2)
+    u, v, x, z = rnd(N1, seed=3), rnd(N2, seed=4), rnd(K, seed=5), rnd(N1, seed=6)
+    C0, y0 = rnd(N1, N2, seed=7), rnd(N1, seed=8)
+    Ad, Bd = (A.t() if ta else A).double(), (B.t() if tb else B).double()
+    ref = 0.75 * Ad @ Bd
+    got = ops.wprod(dev(A), dev(B), ta=ta, tb=tb, alpha=0.75)
+    check(f'wprod[{ta},{tb},{N1}x{N2}x{K}] plain', got, ref, 1e-5)
+    C, y = dev(C0), dev(y0)
+    ops.wprod(dev(A), dev(B), ta=ta, tb=tb, alpha=-1.5, out=C, accumulate=True, u=dev(u), v=dev(v), x=dev(x), y=y,
+              alpha_y=2.0, z=dev(z), beta_z=0.25, y_accumulate=True)
+    check(f'wprod[{ta},{tb},{N1}x{N2}x{K}] C', C, C0.double() - 1.5 * Ad @ Bd + torch.outer(u, v).double(), 1e-5)
+    check(f'wprod[{ta},{tb},{N1}x{N2}x{K}] y', y, y0.double() + 2.0 * Ad @ x.double() + 0.25 * z.double(), 1e-5)
+    _, y2 = ops.wprod(dev(A), dev(B), ta=ta, tb=tb, x=dev(x))
+    check(f'wprod[{ta},{tb},{N1}x{N2}x{K}] y plain', y2, Ad @ x.double(), 1e-5)
+    again = ops.wprod(dev(A), dev(B), ta=ta, tb=tb, alpha=0.75)
+    assert torch.equal(got, again), 'wprod is not deterministic'
+
+
 # --------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('D', [128, 768, 1024])

@@ -61,6 +61,58 @@ def test_fused_step_matches_torch(kind, clip):
             check(f'{kind} clip={clip} step {step} param {i}', pg.detach().cpu(), pr.detach(), 2e-6)
 
 
+@pytest.mark.parametrize('kind', ['sgd', 'adamw'])
+def test_checkpoint_resume_matches_torch(kind):
+    """Save after two updates, load into FRESH optimizers (the fused one and torch's), continue: the AdamW bias correction
+    continues from update 3 (the update count travels in the state dict the way torch keeps it), the device table
+    follows the loaded state tensors, and state dicts move between the fused classes and torch.optim in both
+    directions (a reference checkpoint resumes here and vice versa)."""
+    from vtx import optim
+    init = _params(2)
+    mk_ref = (lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.05)) if kind == 'sgd' else \
+        (lambda ps: torch.optim.AdamW(ps, lr=0.01, betas=(0.9, 0.999), weight_decay=0.05))
+    mk_gpu = (lambda ps: optim.FusedSGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.05)) if kind == 'sgd' else \
+        (lambda ps: optim.FusedAdamW(ps, lr=0.01, betas=(0.9, 0.999), weight_decay=0.05))
+    p_ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    p_gpu = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    o_ref, o_gpu = mk_ref(p_ref), mk_gpu(p_gpu)
+
+    def run(o_r, o_g, steps, first):
+        for step in range(first, first + steps):
+            grads = _params(20 + step)
+            for pr, pg, g in zip(p_ref, p_gpu, grads):
+                pr.grad = g.clone().double()
+                pg.grad = g.clone().to(DEV)
+            o_r.step()
+            o_g.step()
+
+    run(o_ref, o_gpu, 2, 0)
+    sd_ref, sd_gpu = o_ref.state_dict(), o_gpu.state_dict()
+    assert all(float(st['step']) == 2.0 for st in sd_gpu['state'].values())
+    # fresh optimizers over the same parameters; the fused one resumes from ITS state dict, torch from torch's
+    o_ref2, o_gpu2 = mk_ref(p_ref), mk_gpu(p_gpu)
+    o_ref2.load_state_dict(sd_ref)
+    o_gpu2.load_state_dict(sd_gpu)
+    run(o_ref2, o_gpu2, 2, 2)
+    for i, (pr, pg) in enumerate(zip(p_ref, p_gpu)):
+        check(f'{kind} resumed param {i}', pg.detach().cpu(), pr.detach(), 2e-6)
+    # cross-loading: torch's state dict (float64 here -> cast by load_state_dict) into the fused class, and back
+    o_gpu3 = mk_gpu(p_gpu)
+    o_gpu3.load_state_dict(o_ref2.state_dict())
+    o_ref3 = mk_ref(p_ref)
+    o_ref3.load_state_dict(o_gpu2.state_dict())
+    run(o_ref3, o_gpu3, 1, 4)
+    for i, (pr, pg) in enumerate(zip(p_ref, p_gpu)):
+        check(f'{kind} cross-loaded param {i}', pg.detach().cpu(), pr.detach(), 2e-6)
+    # a step after load_state_dict must not touch the OLD state tensors (the device table was rebuilt)
+    old_state = [t for st in o_gpu2.state.values() for t in st.values() if torch.is_tensor(t)]
+    snap = [t.clone() for t in old_state]
+    import copy
+    o_gpu2.load_state_dict(copy.deepcopy(o_gpu2.state_dict()))      # new state tensors
+    run(mk_ref(p_ref), o_gpu2, 1, 5)
+    assert all(torch.equal(a, b) for a, b in zip(old_state, snap)), 'the kernel wrote through stale state pointers'
+
+
 def test_grad_norm_is_the_reference_statistic():
     from vtx import optim
     ps = [torch.nn.Parameter(t.to(DEV)) for t in _params(3)]

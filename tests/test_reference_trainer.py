@@ -69,24 +69,30 @@ def test_reference_lightning_module_builds_on_the_drop_in_modules(arch):
     assert m.no_weight_decay_keywords() == m.model.no_weight_decay_keywords()
 
 
-def test_drop_in_mixup_equals_the_reference_draw_for_draw():
-    """mixup.Mixup of this package (CPU path = the formulas, CUDA path = kernels proven equal to them in
-    tests/test_gpu_head.py) against the reference's class under the same numpy seed."""
+def test_drop_in_mixup_plans_a_batch_like_the_reference_draw_for_draw():
+    """The host half of mixup.Mixup (``draw``) against the reference's class under the same numpy seed: same lambda, same
+    CutMix box, same generator state afterwards (reference mixup.py:74-88,:105-109).  The device half is proven equal to
+    the reference's tensor formulas in tests/test_gpu_head.py; this package has no CPU tensor path."""
     import numpy as np
-    import torch
     import mixup as ours
     spec = importlib.util.spec_from_file_location('ref_mixup', os.path.join(ref_loader.REF_DIR, 'mixup.py'))
     ref = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref)
-    g = torch.Generator().manual_seed(1)
-    x0 = torch.randn(4, 2, 3, 16, 16, generator=g)
-    y0 = torch.tensor([1, 5, 5, 11])
+    shape = (4, 6, 16, 16)
     kinds = set()
-    for seed in range(8):
-        np.random.seed(seed)
-        xr, yr = ref.Mixup(num_classes=12)(x0.clone(), y0)
-        np.random.seed(seed)
-        xo, yo = ours.Mixup(num_classes=12)(x0.clone(), y0)
-        assert torch.equal(xo, xr) and torch.equal(yo, yr), seed
-        kinds.add(bool((xr != x0).flatten(1).all(1).any()))      # mixup changes every element, cutmix only a box
-    assert kinds == {True, False}, 'both branches must have been exercised'
+    for kw in (dict(), dict(cutmix_alpha=0.), dict(mixup_alpha=0.), dict(prob=0.5), dict(correct_lam=False)):
+        for seed in range(8):
+            np.random.seed(seed)
+            rm = ref.Mixup(num_classes=12, **kw)
+            lam_r, cut = rm._params_per_batch()
+            box_r = None
+            if lam_r != 1. and cut:
+                box_r, lam_r = ref.cutmix_bbox_and_lam(shape, lam_r, correct_lam=rm.correct_lam)
+            state_r = np.random.get_state()[1].copy()
+            np.random.seed(seed)
+            lam_o, box_o = ours.Mixup(num_classes=12, **kw).draw(shape)
+            assert np.array_equal(np.random.get_state()[1], state_r), (kw, seed)
+            assert float(lam_o) == float(lam_r), (kw, seed)
+            assert (box_o is None) == (box_r is None) and (box_o is None or box_o == tuple(int(v) for v in box_r)), (kw, seed)
+            kinds.add(box_o is not None)
+    assert kinds == {True, False}, 'both kinds of plan must have been exercised'

@@ -719,10 +719,9 @@ int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const 
   if (options().attn_hw_bwd > 0) {
     const int w = hw_waves(options().attn_hw_bwd, p.H);
     const size_t lds = (size_t)w * SM_WAVE_LDS_BWD;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_launch_on_device(attr_set)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_small_kernel<true>, dim3(ntiles, (p.H + w - 1) / w), dim3(64 * w), lds, st, p, ntiles,
                        (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include "../../include/vtx.h"
 
@@ -193,6 +194,15 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
       return (code);                        \
     }                                       \
   } while (0)
+
+// hipFuncSetAttribute applies to the CURRENT device only: a kernel that needs more than 64 KB of dynamic LDS is
+// configured once per (instantiation, device).  `seen` is the call site's static mask; true = configure it now.
+inline bool first_launch_on_device(std::atomic<unsigned long long>& seen) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  return (seen.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+}
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -336,11 +336,10 @@ static int launch_ring(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   const size_t ring_bytes = (size_t)NBUF * (RBM + BN) * BK * 2;
   const size_t stage_bytes = (size_t)WM * 2 * 32 * STAGE_LD * 4;
   const size_t lds = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  if (first_launch_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_ring_kernel<WM, NBUF, BK>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const int tiles_m = cdiv(d->M, RBM), tiles_n = cdiv(d->N, BN);
   hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<WM, NBUF, BK>), dim3(tiles_m * tiles_n), dim3(WM * 128), lds, st, d->M, d->N,
@@ -998,11 +997,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 
 template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT>
 static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st, const Options& cfg) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  if (first_launch_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         PP_LDS_BYTES);
-    attr_set = true;
   }
   const int tiles_m = cdiv(d->M, PP_BM), tiles_n = cdiv(d->N, PP_BN);
   // column tiles per group (tools/gemm_cg.py, M = 100352: 1 is 15 % slower at N = 3072, 3..8 are within noise;

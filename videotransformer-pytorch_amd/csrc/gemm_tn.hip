@@ -1131,11 +1131,10 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
       const int s_p = tp_splits(d->M, d->N1, d->N2);
       const int m_per_p = (d->M / s_p) / TP_BK * TP_BK;        // the last split also takes the remainder
       const int s_eff = s_p;
-      static bool attr_set_p = false;
-      if (!attr_set_p) {
+      static std::atomic<unsigned long long> attr_set_p{0};
+      if (first_launch_on_device(attr_set_p)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES);
-        attr_set_p = true;
       }
       if (m_per_p >= 2 * TP_BK) {
         out.slab_stride = w_elems + (long)t2p * d->N1; out.cs_fold = t2p;
@@ -1166,10 +1165,9 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
       int m_per_r = cdiv(cdiv(d->M, s_r), TR_BKM) * TR_BKM;
       const size_t ring_bytes = (size_t)TR_NBUF * TR_STAGE * 2;
       const size_t lds_r = ring_bytes > (size_t)8 * 32 * STAGE_LD * 4 ? ring_bytes : (size_t)8 * 32 * STAGE_LD * 4;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static std::atomic<unsigned long long> attr_set{0};
+      if (first_launch_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-        attr_set = true;
       }
       out.slab_stride = w_elems + (long)tiles2 * d->N1; out.cs_fold = tiles2;
       hipLaunchKernelGGL(gemm_tn_bf16_ring_kernel, dim3(tiles1r * tiles2 * s_r), dim3(512), lds_r, st, d->M, m_per_r,

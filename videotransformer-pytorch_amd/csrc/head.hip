@@ -79,32 +79,43 @@ __global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__
     for (int c = lane; c < C; c += 64) acc += tr[c] * (lse - xr[c]);
     acc = wave_sum(acc);
   } else {
-    acc = lse - xr[labels[row]];
+    const long lab = labels[row];                // outside [0, C) (nn.CrossEntropyLoss's ignore_index = -100 included): not counted
+    acc = (lab >= 0 && lab < C) ? lse - xr[lab] : 0.f;
   }
   if (lane == 0) { loss_row[row] = acc; lse_out[row] = lse; }
 }
 
-// out[0] = mean of rows[0..B) in a fixed order (one workgroup)
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ rows, int B, float* __restrict__ out) {
+// out[0] = mean of the counted rows of rows[0..B) in a fixed order (one workgroup), out[1] = their number: with labels,
+// rows whose label lies outside [0, C) are not counted (torch's mean over the non-ignored rows; all ignored: 0 / 0 = nan)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ rows, const long* __restrict__ labels, int B, int C,
+                                                        float* __restrict__ out) {
   __shared__ float red[256];
+  __shared__ int cnt[256];
   float a = 0.f;
-  for (int i = threadIdx.x; i < B; i += 256) a += rows[i];
+  int n = 0;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    a += rows[i];
+    n += labels ? (labels[i] >= 0 && labels[i] < C) : 1;
+  }
   red[threadIdx.x] = a;
+  cnt[threadIdx.x] = n;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    if ((int)threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; cnt[threadIdx.x] += cnt[threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+  if (threadIdx.x == 0) { out[0] = red[0] / (float)cnt[0]; out[1] = (float)cnt[0]; }
 }
 
 // dx[b][c] = g * (softmax(x[b])[c] * sum_c t[b][c] - t[b][c]),  g = dloss / B  (mean reduction)
 __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ x, const float* __restrict__ soft,
                                                        const long* __restrict__ labels, const float* __restrict__ lse, int B, int C,
-                                                       float g, const float* __restrict__ gdev, float* __restrict__ dx) {
+                                                       float g, const float* __restrict__ gdev, const float* __restrict__ count,
+                                                       float* __restrict__ dx) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   if (gdev) g *= gdev[0];                       // upstream gradient of the scalar loss, read on the device (no host sync)
+  if (count) g /= count[0];                     // mean over the counted rows (forward's loss_mean[1])
   const float* xr = x + (long)row * C;
   float ts = 1.f;
   if (soft) {
@@ -114,6 +125,10 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__
   }
   const float l = lse[row];
   const long lab = soft ? -1 : labels[row];
+  if (!soft && (lab < 0 || lab >= C)) {         // not counted: no gradient
+    for (int c = lane; c < C; c += 64) dx[(long)row * C + c] = 0.f;
+    return;
+  }
   for (int c = lane; c < C; c += 64) {
     const float t = soft ? soft[(long)row * C + c] : (c == lab ? 1.f : 0.f);
     dx[(long)row * C + c] = g * (expf(xr[c] - l) * ts - t);
@@ -128,6 +143,7 @@ __global__ __launch_bounds__(256) void topk_correct_kernel(const float* __restri
   if (row >= B) return;
   const float* xr = x + (long)row * C;
   const long lab = labels[row];
+  if (lab < 0 || lab >= C) return;              // no such class: never correct
   const float v = xr[lab];
   int ahead = 0;
   for (int c = lane; c < C; c += 64) ahead += (xr[c] > v) || (xr[c] == v && c < lab);
@@ -174,16 +190,16 @@ extern "C" int vtx_softmax_xent_fwd(const float* logits, const float* soft_targe
   hipLaunchKernelGGL(xent_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), logits, soft_targets, labels, B, C, loss_rows, lse);
   int rc = check_launch("softmax_xent_fwd");
   if (rc || !loss_mean) return rc;
-  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, as_stream(stream), loss_rows, B, loss_mean);
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, as_stream(stream), loss_rows, labels, B, C, loss_mean);
   return check_launch("softmax_xent_mean");
 }
 
 extern "C" int vtx_softmax_xent_bwd(const float* logits, const float* soft_targets, const long* labels, const float* lse, int B, int C,
-                                    float grad_scale, const float* grad_loss, float* dlogits, void* stream) {
+                                    float grad_scale, const float* grad_loss, const float* count, float* dlogits, void* stream) {
   VTX_REQUIRE(logits && lse && dlogits && B > 0 && C > 0 && ((soft_targets != nullptr) != (labels != nullptr)), VTX_EINVAL,
               "softmax_xent_bwd: give either soft targets or labels");
   hipLaunchKernelGGL(xent_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), logits, soft_targets, labels, lse, B, C, grad_scale,
-                     grad_loss, dlogits);
+                     grad_loss, count, dlogits);
   return check_launch("softmax_xent_bwd");
 }
 

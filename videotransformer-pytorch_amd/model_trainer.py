@@ -89,7 +89,16 @@ class Accuracy:
         return (self.correct - before).float() / scores.shape[0]
 
     def compute(self):
-        return self.correct.float() / max(self.total, 1) if self.correct is not None else torch.zeros(())
+        """Accuracy over everything seen since reset() -- over ALL data-parallel ranks when a process group is up, as
+        torchmetrics synchronises its states in compute() (the reference selects its best checkpoint from this value)."""
+        if self.correct is None:
+            return torch.zeros(())
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            st = torch.stack([self.correct.float(), torch.tensor(float(self.total), device=self.correct.device)])
+            dist.all_reduce(st)
+            return st[0] / st[1].clamp(min=1.0)
+        return self.correct.float() / max(self.total, 1)
 
     def reset(self):
         self.correct, self.total = None, 0

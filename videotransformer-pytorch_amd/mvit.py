@@ -142,6 +142,25 @@ class MultiscaleVisionTransformers(nn.Module):
         self.cls_positional_encoding = cls_positional_encoding
         self.blocks = blocks
         self.norm_embed = norm_embed
+        self._init_vit_weights()
+
+    def _init_vit_weights(self, std=0.02):
+        """What pytorchvideo's constructor ends with -- ``init_net_weights(self, init_std=0.02, style='vit')`` (restated
+        from the package, which is on no disk here: parity unpinned like the rest of the backbone): truncated-normal Linear
+        weights with zero biases, LayerNorm at (1, 0), truncated-normal cls token and separable position embeddings.
+        MaskFeat pretraining always starts from this state (reference video_transformer.py:844-864 then re-initialises
+        only patch_embed, decoder_pred and mask_token); the depthwise pooling convolutions keep nn.Conv3d's default."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=std)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+            elif isinstance(m, SpatioTemporalClsPositionalEncoding):
+                for w in m.parameters():
+                    nn.init.trunc_normal_(w, std=std)
 
     def forward(self, x):
         x = self.cls_positional_encoding(_compute(x))

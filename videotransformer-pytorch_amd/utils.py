@@ -1,7 +1,7 @@
 """Helpers of the reference utils.py under the same names (rank helpers :11-34, timing :36-40,
 parameter listing / grouping :42-65, denormalisation and clip plotting :68-127), without its
 top-level pytorch_lightning / matplotlib imports: ``import utils`` must work wherever the drop-in
-modules do; matplotlib is imported only by the plotting helper that needs it.
+modules do.
 """
 import os
 import os.path as osp
@@ -66,21 +66,3 @@ def denormalize(data, mean, std):
         return v[None, :] if v.shape else v
     shape = data.shape
     return (data.contiguous().view(-1, shape[-1]) * as_row(std) + as_row(mean)).view(shape)
-
-
-def show_processed_image(imgs, save_dir, mean, std, index=0):
-    """Save the first 5 frames of every row of ``imgs`` ([T,H,W,C] tensors or lists of them),
-    de-normalised, as ``clip_transformed_b{index}.png`` under ``save_dir``."""
-    import matplotlib.pyplot as plt
-    os.makedirs(save_dir, exist_ok=True)
-    if not isinstance(imgs[0], list):
-        imgs = [imgs]
-    n_cols = 5
-    fig, axs = plt.subplots(nrows=len(imgs), ncols=n_cols, squeeze=False)
-    for r, row in enumerate(imgs):
-        for c, img in enumerate(row[:n_cols]):
-            frame = (denormalize(img, mean, std).cpu().numpy() * 255).astype(np.uint8)
-            axs[r, c].imshow(np.asarray(frame))
-            axs[r, c].set(xticklabels=[], yticklabels=[], xticks=[], yticks=[])
-    plt.tight_layout()
-    plt.savefig(osp.join(save_dir, f'clip_transformed_b{index}.png'))

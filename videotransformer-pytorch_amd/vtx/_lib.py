@@ -51,6 +51,19 @@ class GemmTnDesc(C.Structure):
     ]
 
 
+class WprodDesc(C.Structure):
+    _fields_ = [
+        ('N1', C.c_int), ('N2', C.c_int), ('K', C.c_int),
+        ('A', C.c_void_p), ('a_rs', C.c_long), ('a_ks', C.c_long),
+        ('B', C.c_void_p), ('b_ks', C.c_long), ('b_cs', C.c_long),
+        ('alpha', C.c_float),
+        ('C', C.c_void_p), ('ldc', C.c_long), ('accumulate', C.c_int),
+        ('u', C.c_void_p), ('v', C.c_void_p),
+        ('x', C.c_void_p), ('y', C.c_void_p),
+        ('alpha_y', C.c_float), ('z', C.c_void_p), ('beta_z', C.c_float), ('y_accumulate', C.c_int),
+    ]
+
+
 class CtTensor(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst_c', C.c_void_p), ('dst_t', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int)]
 
@@ -105,6 +118,7 @@ SIGNATURES = {
     'vtx_gemm_nt': (ci, [C.POINTER(GemmDesc), vp]),
     'vtx_gemm_tn_workspace': (sz, [ci, ci, ci]),
     'vtx_gemm_tn': (ci, [C.POINTER(GemmTnDesc), vp]),
+    'vtx_wprod': (ci, [C.POINTER(WprodDesc), vp]),
     'vtx_colsum_workspace': (sz, [ci, ci]),
     'vtx_colsum': (ci, [ci, ci, ci, vp, cl, RowMap, vp, ci, vp, sz, vp]),
     'vtx_attn_fwd': (ci, [C.POINTER(AttnDesc), vp]),
@@ -145,7 +159,7 @@ SIGNATURES = {
     'vtx_cutmix_batch': (ci, [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     'vtx_mixup_target': (ci, [vp, ci, ci, cf, cf, cf, cf, vp, vp]),
     'vtx_softmax_xent_fwd': (ci, [vp, vp, vp, ci, ci, vp, vp, vp, vp]),
-    'vtx_softmax_xent_bwd': (ci, [vp, vp, vp, vp, ci, ci, cf, vp, vp, vp]),
+    'vtx_softmax_xent_bwd': (ci, [vp, vp, vp, vp, ci, ci, cf, vp, vp, vp, vp]),
     'vtx_topk_correct': (ci, [vp, vp, ci, ci, ci, vp, vp]),
     'vtx_mt_chunks': (ci, [cl]),
     'vtx_mt_grad_norms': (ci, [vp, vp, ci, ci, vp, vp, vp]),

@@ -69,6 +69,11 @@ class GradBuckets:
                 # direct gradients: the kernels' own call (vtx.functions._fire) came first; this torch version also
                 # runs a parameter's post-accumulate hooks when the Function returned None for it -- count once
                 if self.direct:
+                    from . import functions
+                    if functions.firing():
+                        raise RuntimeError('GradBuckets(direct=True): a second kernel accumulated into a parameter whose '
+                                           'gradient was already counted (a module applied twice in one backward); its '
+                                           "bucket's all-reduce may already be running -- use direct=False for such models")
                     return
                 raise RuntimeError('GradBuckets: a second gradient arrived for a parameter whose bucket was already '
                                    'counted -- call zero() before every backward (one backward per step)')

@@ -74,8 +74,14 @@ def restage_weights(params):
             tabs = (key, tab_dev, starts_dev, n_tiles)
             _restage_tables[(dtype, dev)] = tabs
         ops.mt_cast_transpose(dtype, tabs[1], tabs[2], len(ents), tabs[3])
-        for p, hit, _, _ in ents:
+        for p, hit, wc, wt in ents:
             _wcache[(id(p), dtype)] = (hit[0], (p._version, p.data_ptr(), p.device), hit[2], hit[3])
+            # the copies were rewritten behind autograd's back: bump their version counters (an in-place no-op on a
+            # zero-element view, no launch), so that a graph that saved them BEFORE this update -- optimizer.step() between
+            # a forward and its backward -- fails with autograd's "modified by an inplace operation" error, not silently
+            for t in (wc, wt):
+                if t is not None:
+                    t.view(-1)[:0].zero_()
 
 
 _mcache = {}
@@ -89,27 +95,25 @@ def set_merge_temporal_fc(on):
     _merge_tfc = bool(on)
 
 
-def merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtype, need_t):
+def merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtype, need_t, c=1.0):
     """attn.proj followed by temporal_fc is linear in the attention output (only a per-sequence DropPath scale sits
-    between them): W_c = W_tfc W_proj, b_c = W_tfc b_proj, in fp32 from the fp32 parameters (plain library products,
-    weights x weights: these and the mapping of the merged weight gradient back to the two layers in
-    TimeAttnFn.backward are the only rocBLAS calls of the path), staged like any other weight.  Returns
-    (W_c, W_c^T, b_c); cached while the four parameters are unchanged (same validity rule as ``weights``)."""
+    between them): W_c = W_tfc W_proj and the epilogue bias b_c + b_tfc / c with b_c = W_tfc b_proj, in fp32 from the
+    fp32 parameters by ONE vtx_wprod launch (exact-fp32 matrix instruction; weights x weights, no activation passes
+    through it), staged like any other weight.  Returns (W_c, W_c^T, bias); cached while the four parameters and the
+    keep scale c are unchanged (same validity rule as ``weights``)."""
     ps = (proj_w, proj_b, tfc_w, tfc_b)
     key = (id(proj_w), id(tfc_w), dtype)
-    stamp = tuple((p._version, p.data_ptr(), p.device) for p in ps)
+    stamp = tuple((p._version, p.data_ptr(), p.device) for p in ps) + (float(c),)
     hit = _mcache.get(key)
     if hit is not None and all(r() is p for r, p in zip(hit[0], ps)) and hit[1] == stamp and (hit[3] is not None or not need_t):
         return hit[2], hit[3], hit[4]
-    with torch.no_grad(), torch.autocast('cuda', enabled=False):   # fp32 products also inside an autocast region
-        wc32 = torch.mm(tfc_w.detach().float(), proj_w.detach().float())
-        bc = torch.mv(tfc_w.detach().float(), proj_b.detach().float())
+    wc32, bias = ops.wprod(tfc_w.detach(), proj_w.detach(), x=proj_b.detach(), z=tfc_b.detach(), beta_z=1.0 / float(c))
     wc, wt = ops.cast_transpose(wc32, dtype, want_c=True, want_t=need_t)
     if len(_mcache) > 1024:
         for k in [k for k, v in _mcache.items() if any(r() is None for r in v[0])]:
             del _mcache[k]
-    _mcache[key] = (tuple(weakref.ref(p) for p in ps), stamp, wc, wt, bc)
-    return wc, wt, bc
+    _mcache[key] = (tuple(weakref.ref(p) for p in ps), stamp, wc, wt, bias)
+    return wc, wt, bias
 
 
 def clear_weight_cache():
@@ -151,12 +155,27 @@ def _sink(p):
     return g
 
 
+_firing = False      # True while _fire() runs the hooks: lets a hook tell the kernels' own call from autograd's
+
+
 def _fire(*params):
-    for p in params:
-        hooks = getattr(p, '_post_accumulate_grad_hooks', None)
-        if hooks:
-            for h in list(hooks.values()):
-                h(p)
+    global _firing
+    _firing = True
+    try:
+        for p in params:
+            hooks = getattr(p, '_post_accumulate_grad_hooks', None)
+            if hooks:
+                for h in list(hooks.values()):
+                    h(p)
+    finally:
+        _firing = False
+
+
+def firing():
+    """True inside a hook call made by the direct-gradient kernels themselves (vtx.dp.GradBuckets uses it to tell a second
+    accumulation into an already counted parameter -- a module applied twice in one backward -- from autograd's own
+    duplicate hook call for the None the Function returned)."""
+    return _firing
 
 
 def _linear_grads(w, b, A, Bm, M, N1, N2, **kw):
@@ -230,9 +249,8 @@ class TimeAttnFn(torch.autograd.Function):
         ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, T, heads, hd, scale)
         out = torch.empty_like(x)
         if merged:
-            wc, wcT, bc = merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtp, need_t)
             c = 1.0 if scale_vec is None else float(keep_scale)
-            bias = torch.add(bc, tfc_b.detach().float(), alpha=1.0 / c)
+            wc, wcT, bias = merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtp, need_t, c)
             ops.gemm_nt(o, wc, out, M, D, D, cmap=tm, bias=bias, R=x, rmap=tm, row_scale=scale_vec, rs=(T, 1, 1, 0))
             if scale_vec is not None:
                 ops.dropped_rows_fix(scale_vec, M, D, T, x=x, xmap=tm, bias=tfc_b.detach(), out=out, omap=tm, zero=o)
@@ -272,24 +290,27 @@ class TimeAttnFn(torch.autograd.Function):
             c = float(keep_scale) if has_scale else 1.0
             G, cs_all = ops.gemm_tn(dout, o, M, D, D, amap=tm, want_colsum=True)
             ops.gemm_nt(dout, wcT, do, M, D, D, amap=tm, row_scale=sv, rs=(T, 1, 1, 0))
-            if has_scale:
+            if has_scale:                              # u = c * (colsum(dout) - colsum over the dropped rows of dout)
                 part = ops.dropped_rows_colsum(dout, sv, M, D, T, smap=tm)
-                u = cs_all * c
+                u = ops.reduce_rows(cs_all, 1, 1, D, D, 0, 1, 0, scale=c)
                 ops.reduce_rows(part, 1, part.shape[0], D, D, 0, 1, 0, out=u, scale=-c, accumulate=True)
+                u = u.view(-1)
             else:
                 u = cs_all
+            # the merged weight gradient G mapped back to the two Linear layers (vtx_wprod: fp32, weights x weights):
+            #   dW_tfc = c G W_proj^T + u b_proj^T,   dW_proj = c W_tfc^T G,   db_proj = W_tfc^T u,   db_tfc = colsum(dout)
             pw, pb, tw = p_proj_w.detach(), p_proj_b.detach(), p_tfc_w.detach()
-            with torch.autocast('cuda', enabled=False):
-                d_tfc_w = torch.addr(torch.mm(G, pw.t()).mul_(c), u, pb)
-                d_tfc_b = cs_all
-                d_proj_w = torch.mm(tw.t(), G).mul_(c)
-                d_proj_b = torch.mv(tw.t(), u)
             sinks = [_sink(p) for p in (p_tfc_w, p_tfc_b, p_proj_w, p_proj_b)]
-            if all(g is not None for g in sinks):      # the same `grad += new` autograd would do
-                for g, d in zip(sinks, (d_tfc_w, d_tfc_b, d_proj_w, d_proj_b)):
-                    g.add_(d)
+            if all(g is not None for g in sinks):      # the same `grad += new` autograd would do, inside the kernels
+                ops.wprod(G, pw, tb=True, alpha=c, u=u, v=pb, out=sinks[0], accumulate=True)
+                ops.wprod(tw, G, ta=True, alpha=c, out=sinks[2], accumulate=True, x=u, y=sinks[3], y_accumulate=True)
+                ops.reduce_rows(cs_all, 1, 1, D, D, 0, 1, 0, out=sinks[1].view(1, D), accumulate=True)
                 _fire(p_tfc_w, p_tfc_b, p_proj_w, p_proj_b)
                 d_tfc_w = d_tfc_b = d_proj_w = d_proj_b = None
+            else:
+                d_tfc_w = ops.wprod(G, pw, tb=True, alpha=c, u=u, v=pb)
+                d_proj_w, d_proj_b = ops.wprod(tw, G, ta=True, alpha=c, x=u)
+                d_tfc_b = cs_all
         else:
             wpT, wtT = wrest
             # temporal_fc
@@ -803,7 +824,9 @@ class RowScaleFn(torch.autograd.Function):
 class SoftmaxXentFn(torch.autograd.Function):
     """mean_b sum_c -t[b,c] log_softmax(logits[b])[c]: ``target`` is an int64 label vector [B]
     (nn.CrossEntropyLoss, reference model_trainer.py:91) or a float [B,C] soft-target matrix (timm's
-    SoftTargetCrossEntropy after Mixup, :87-88).  fp32 logits."""
+    SoftTargetCrossEntropy after Mixup, :87-88).  fp32 logits.  Labels outside [0, C) -- nn.CrossEntropyLoss's default
+    ignore_index = -100 -- contribute no loss and no gradient and are left out of the mean's denominator (decided on the
+    device: no host synchronisation)."""
 
     @staticmethod
     def forward(ctx, logits, target):
@@ -821,21 +844,22 @@ class SoftmaxXentFn(torch.autograd.Function):
             target = target.long().contiguous()
         rows = torch.empty(B, dtype=torch.float32, device=logits.device)
         lse = torch.empty(B, dtype=torch.float32, device=logits.device)
-        mean = torch.empty((), dtype=torch.float32, device=logits.device)
+        mean = torch.empty(2, dtype=torch.float32, device=logits.device)       # [mean, counted rows]
         ops.call('vtx_softmax_xent_fwd', ops.ptr(logits), ops.ptr(target) if soft else None, None if soft else ops.ptr(target),
                  B, Cn, ops.ptr(rows), ops.ptr(lse), ops.ptr(mean), ops.stream())
-        ctx.save_for_backward(logits, target, lse)
+        ctx.save_for_backward(logits, target, lse, mean)
         ctx.soft = soft
-        return mean
+        return mean[0]
 
     @staticmethod
     def backward(ctx, gloss):
-        logits, target, lse = ctx.saved_tensors
+        logits, target, lse, mean = ctx.saved_tensors
         B, Cn = logits.shape
         d = torch.empty_like(logits)
         gloss = gloss.float().contiguous()          # stays on the device: no host sync inside backward
         ops.call('vtx_softmax_xent_bwd', ops.ptr(logits), ops.ptr(target) if ctx.soft else None,
-                 None if ctx.soft else ops.ptr(target), ops.ptr(lse), B, Cn, 1.0 / B, ops.ptr(gloss), ops.ptr(d), ops.stream())
+                 None if ctx.soft else ops.ptr(target), ops.ptr(lse), B, Cn, 1.0, ops.ptr(gloss), mean.data_ptr() + 4, ops.ptr(d),
+                 ops.stream())
         return d, None
 
 

@@ -219,6 +219,45 @@ def gemm_tn(A, B, M, N1, N2, out=None, lda=None, ldb=None, amap=IDENT, bmap=IDEN
     return (out, cs) if want_colsum else out
 
 
+def wprod(A, B, ta=False, tb=False, out=None, alpha=1.0, accumulate=False, u=None, v=None, x=None, y=None, alpha_y=1.0,
+          z=None, beta_z=0.0, y_accumulate=False):
+    """out (+)= alpha * op(A) @ op(B) (+ u v^T) on contiguous fp32 matrices, op = transpose when ta / tb; with x also
+    y (+)= alpha_y * op(A) @ x + beta_z * z (y is allocated when None).  Returns out, or (out, y).  See vtx_wprod."""
+    need_cuda(A, B, out, u, v, x, y, z)
+    for t in (A, B, out, u, v, x, y, z):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise TypeError('wprod: contiguous float32 tensors expected')
+    d = _lib.WprodDesc()
+    ar, ac = A.shape
+    br, bc = B.shape
+    if ta:
+        d.N1, K, d.a_rs, d.a_ks = ac, ar, 1, ac
+    else:
+        d.N1, K, d.a_rs, d.a_ks = ar, ac, ac, 1
+    if tb:
+        Kb, d.N2, d.b_ks, d.b_cs = bc, br, 1, bc
+    else:
+        Kb, d.N2, d.b_ks, d.b_cs = br, bc, bc, 1
+    if K != Kb:
+        raise ValueError(f'wprod: inner dimensions differ ({K} vs {Kb})')
+    d.K = K
+    if out is None:
+        if accumulate:
+            raise ValueError('wprod: accumulate needs an output tensor')
+        out = torch.empty(d.N1, d.N2, dtype=torch.float32, device=A.device)
+    if x is not None and y is None:
+        if y_accumulate:
+            raise ValueError('wprod: y_accumulate needs y')
+        y = torch.empty(d.N1, dtype=torch.float32, device=A.device)
+    d.A, d.B, d.C, d.ldc = ptr(A), ptr(B), ptr(out), d.N2
+    d.alpha, d.accumulate = float(alpha), int(bool(accumulate))
+    d.u, d.v, d.x, d.y, d.z = ptr(u), ptr(v), ptr(x), ptr(y), ptr(z)
+    d.alpha_y, d.beta_z, d.y_accumulate = float(alpha_y), float(beta_z), int(bool(y_accumulate))
+    with _timed('wprod', 2.0 * d.N1 * d.N2 * K, 4.0 * (d.N1 * K + K * d.N2 + d.N1 * d.N2), f'{d.N1}x{d.N2}x{K}'):
+        call('vtx_wprod', C.byref(d), stream())
+    return out if x is None else (out, y)
+
+
 def colsum(A, M, N, lda=None, amap=IDENT, out=None, accumulate=False):
     need_cuda(A)
     if out is None:

@@ -121,6 +121,32 @@ class _FusedBase(torch.optim.Optimizer):
     def _launch(self, clip):
         raise NotImplementedError
 
+    # ---- checkpoint surface ----------------------------------------------------------------------
+    # The device table holds raw pointers to the state tensors: anything that replaces them (load_state_dict) or adds
+    # parameters (add_param_group) must rebuild it.  The update count lives in the state dict the way torch keeps it
+    # (a per-parameter 'step' entry), so that a resumed AdamW continues with the right bias correction and state dicts
+    # move between these classes and torch.optim.SGD / AdamW.
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._key = None
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            st['step'] = torch.tensor(float(self._n_steps))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = set()
+        for st in self.state.values():
+            if 'step' in st:
+                steps.add(int(float(st.pop('step'))))
+        if len(steps) > 1:
+            raise NotImplementedError(f'vtx.optim: one update count for all parameters expected, the state dict holds {sorted(steps)}')
+        self._n_steps = steps.pop() if steps else 0
+        self._key = None                                # the loaded state tensors are new tensors
+
 
 class FusedSGD(_FusedBase):
     """torch.optim.SGD(lr, momentum, nesterov, weight_decay; dampening 0) as one multi-tensor kernel."""
