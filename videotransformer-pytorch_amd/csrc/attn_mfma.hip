@@ -124,6 +124,55 @@ __device__ inline bf16x8 frag_cols_o(const bf16raw* lds, int row0, int n2, const
   return u.v;
 }
 
+// Row addressing of one sequence in closed form: row(i) = i == 0 ? row0 : base + i * stride (contiguous sequences:
+// row0 = base, stride 1; divided spatial attention: row 0 is the clip's cls row / its per-frame copy, token i >= 1 sits
+// i * T rows further).  in_row / out_row (attn_common.h) compute the same rows with a division per call; per lane and row
+// that was ~40 vector instructions around every fragment load and row store of kernels bound by vector-ALU issue.
+struct RowLin { long row0, base, stride; };
+__device__ inline RowLin lin_in(const AttnP& p, int s) {
+  RowLin r;
+  if (p.mode == VTX_ATTN_CONTIG) { r.base = (long)s * p.L; r.stride = 1; r.row0 = r.base; return r; }
+  const int b = s / p.T, t = s - b * p.T;
+  r.row0 = (long)b * (1 + (long)p.P * p.T);
+  r.stride = p.T;
+  r.base = r.row0 + 1 + t - r.stride;           // row(i) = row0 + 1 + (i - 1) * T + t
+  return r;
+}
+__device__ inline RowLin lin_out(const AttnP& p, int s) {
+  RowLin r;
+  if (p.mode == VTX_ATTN_CONTIG) { r.base = (long)s * p.L; r.stride = 1; r.row0 = r.base; return r; }
+  const int b = s / p.T, t = s - b * p.T;
+  r.row0 = (long)p.B * p.P * p.T + s;
+  r.stride = p.T;
+  r.base = (long)b * p.P * p.T + t - r.stride;  // row(i) = b * P * T + (i - 1) * T + t
+  return r;
+}
+__device__ inline long lin_row(const RowLin& r, int i) { return i == 0 ? r.row0 : r.base + (long)i * r.stride; }
+
+// The four row-wise fragments (64 columns) of row `row` of a [.., ld] matrix, column origin col0; rows beyond nvalid read
+// row nvalid - 1 instead (no branch, one address per row): every kernel below keeps a padded query / key in its own lane
+// and never stores its results, so its operands only have to be finite.
+__device__ inline void load_row_frags(bf16x8 (&f)[4], const bf16raw* base, long ld, int col0, const RowLin& rl, int row, int nvalid,
+                                      int lane) {
+  const int rc = row < nvalid ? row : nvalid - 1;
+  const bf16raw* src = base + lin_row(rl, rc) * ld + col0 + 8 * (lane >> 5);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    union { bf16x8 v; uint4 u; } x;
+    x.u = *reinterpret_cast<const uint4*>(src + ks * 16);
+    f[ks] = x.v;
+  }
+}
+// sum_j a[j] * b[j] over the 8 bf16 pairs of two fragments, accumulated into acc (v_dot2c_f32_bf16: exact products, fp32 sum)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+__device__ inline float frag_dot2(const bf16x8& a, const bf16x8& b, float acc) {
+  union { bf16x8 v; bf16x2_ h[4]; } ua, ub;
+  ua.v = a; ub.v = b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_fdot2_f32_bf16(ua.h[j], ub.h[j], acc, false);
+  return acc;
+}
+
 // Row-wise operand fragment straight from global memory (rows beyond nvalid read as zero).
 template <typename RowFn>
 __device__ inline bf16x8 frag_global(const bf16raw* base, long ld, int col0, int row, int nvalid, int ks, int lane, RowFn rowfn) {
@@ -208,19 +257,24 @@ __device__ inline void store_rows_direct(bf16raw* dst_row, const f32x16 (&acc)[2
 // and then by the VALU softmax (v_exp_f32 is quarter rate), so per score element the loop spends
 // one max, one fma, one exp2 and one add: the scale is folded into the fma and the padding mask is
 // applied only to the key tile that actually holds padded keys.
+// NT_ > 0: the number of 32-row tiles is a compile-time constant (7 for the L = 197 of every model here): the key / query
+// tile loops inside a query / key tile are fully unrolled, so every LDS fragment address is a lane-constant register plus an
+// immediate offset.  With a run-time trip count each of the twelve address registers of the loop body was copied and stepped
+// by 4 KB per iteration (24 of ~88 vector instructions per key tile in the dq kernel, which is bound by vector-ALU issue).
+template <int NT_>
 __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                    bf16raw* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  const int nt = NT_ > 0 ? NT_ : (p.L + 31) >> 5, Lp = nt * 32;
   bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Vs = Ks + Lp * 64;
   bf16raw* stg = Vs + Lp * 64 + wave * MA_STAGE_ELEMS;
-  auto rowfn = [&](int i) { return m_in_row(p, s, i); };
+  const RowLin li = lin_in(p, s), lo = lin_out(p, s);
+  auto rowfn = [&](int i) { return lin_row(li, i); };
   bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, wave * 32 + (lane & 31), p.L, ks, lane, rowfn);
+  load_row_frags(qf, qkv, p.ld_qkv, h * 64, li, wave * 32 + (lane & 31), p.L, lane);
   fill_tiles2(Ks, Vs, Lp, p.L, qkv, p.ld_qkv, D + h * 64, rowfn, qkv, p.ld_qkv, 2 * D + h * 64, rowfn);
   __syncthreads();
   const float c2 = p.scale * LOG2E;
@@ -229,12 +283,12 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int qt = wave; qt < nt; qt += 4) {
     bf16x8 qn[4];                                  // next query tile's fragments, in flight during this one
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qn[ks] = frag_global(qkv, p.ld_qkv, h * 64, (qt + 4) * 32 + (lane & 31), p.L, ks, lane, rowfn);
+    load_row_frags(qn, qkv, p.ld_qkv, h * 64, li, (qt + 4) * 32 + (lane & 31), p.L, lane);
     f32x16 acc[2];
     zero16(acc[0]);
     zero16(acc[1]);
     float m = -1e30f, l = 0.f;                     // running max of the RAW scores (scale > 0)
+#pragma unroll(NT_ > 0 ? (NT_ + MA_KB - 1) / MA_KB : 1)
     for (int kb = 0; kb < nt; kb += MA_KB) {
       f32x16 st[MA_KB];                            // (tiles beyond nt stay undefined: every use below is guarded)
 #pragma unroll
@@ -296,7 +350,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
     const int q = qt * 32 + (lane & 31);
     store_rows_T(stg, acc, 1.0f / l, lane, [&](int r) -> bf16raw* {
       const int qq = qt * 32 + r;
-      return qq < p.L ? out + m_out_row(p, s, qq) * p.ld_out + h * 64 : nullptr;
+      return qq < p.L ? out + lin_row(lo, qq) * p.ld_out + h * 64 : nullptr;
     });
     if (q < p.L && lane < 32) lse[((long)s * p.H + h) * p.L + q] = (m * c2) * LN2 + __logf(l);
 #pragma unroll
@@ -305,6 +359,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
 }
 
 // --------------------------------------------------------------------------- backward: dq
+template <int NT_>
 __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                       const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
                                                                       const float* __restrict__ lse, float* __restrict__ delta,
@@ -312,12 +367,16 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  const int nt = NT_ > 0 ? NT_ : (p.L + 31) >> 5, Lp = nt * 32;
   bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Vs = Ks + Lp * 64;
   bf16raw* stg = Vs + Lp * 64 + wave * MA_STAGE_ELEMS;
-  auto rin = [&](int i) { return m_in_row(p, s, i); };
-  auto rout = [&](int i) { return m_out_row(p, s, i); };
+  const RowLin li = lin_in(p, s), lo = lin_out(p, s);
+  auto rin = [&](int i) { return lin_row(li, i); };
+  bf16x8 qf[4], df[4], of[4];                      // this wave's first query tile: Q, dO, O rows (one row per lane)
+  load_row_frags(qf, qkv, p.ld_qkv, h * 64, li, wave * 32 + (lane & 31), p.L, lane);
+  load_row_frags(df, dout, p.ld_dout, h * 64, lo, wave * 32 + (lane & 31), p.L, lane);
+  load_row_frags(of, o, p.ld_out, h * 64, lo, wave * 32 + (lane & 31), p.L, lane);
   fill_tiles2(Ks, Vs, Lp, p.L, qkv, p.ld_qkv, D + h * 64, rin, qkv, p.ld_qkv, 2 * D + h * 64, rin);
   __syncthreads();
   const float c2 = p.scale * LOG2E;
@@ -326,24 +385,24 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int qt = wave; qt < nt; qt += 4) {
     const int q = qt * 32 + (lane & 31);
-    bf16x8 qf[4], df[4];
-    float dl = 0.f;
+    bf16x8 qn[4], dn[4], on[4];                    // the next query tile's rows, in flight during this one
+    load_row_frags(qn, qkv, p.ld_qkv, h * 64, li, q + 128, p.L, lane);
+    load_row_frags(dn, dout, p.ld_dout, h * 64, lo, q + 128, p.L, lane);
+    load_row_frags(on, o, p.ld_out, h * 64, lo, q + 128, p.L, lane);
+    float dl = 0.f;                                // delta = rowsum(dO * O): this lane's 32 of the row's 64 columns
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = frag_global(qkv, p.ld_qkv, h * 64, q, p.L, ks, lane, rin);
-      df[ks] = frag_global(dout, p.ld_dout, h * 64, q, p.L, ks, lane, rout);
-      dl += frag_dot(df[ks], frag_global(o, p.ld_out, h * 64, q, p.L, ks, lane, rout));
-    }
+    for (int ks = 0; ks < 4; ++ks) dl = frag_dot2(df[ks], of[ks], dl);
     dl += __shfl_xor(dl, 32, 64);
-    const long li = ((long)s * p.H + h) * p.L + q;
+    const long lidx = ((long)s * p.H + h) * p.L + q;
     float l2 = 0.f;
     if (q < p.L) {
-      l2 = lse[li] * LOG2E;
-      if (lane < 32) delta[li] = dl;
+      l2 = lse[lidx] * LOG2E;
+      if (lane < 32) delta[lidx] = dl;
     }
     f32x16 acc[2];
     zero16(acc[0]);
     zero16(acc[1]);
+#pragma unroll(NT_ > 0 ? NT_ : 1)
     for (int kt = 0; kt < nt; ++kt) {
       f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, kt * 32, 0, fo), qf[0], zero, 0, 0, 0);
       f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Vs, kt * 32, 0, fo), df[0], zero, 0, 0, 0);
@@ -375,12 +434,15 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
       const int qq = qt * 32 + r;
       if (qq >= p.L) return nullptr;
       return (p.mode == VTX_ATTN_SPACE && qq == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
-                                                    : dqkv + m_in_row(p, s, qq) * p.ld_dqkv + h * 64;
+                                                    : dqkv + lin_row(li, qq) * p.ld_dqkv + h * 64;
     });
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = qn[ks]; df[ks] = dn[ks]; of[ks] = on[ks]; }
   }
 }
 
 // -------------------------------------------------------------------------- backward: dk, dv
+template <int NT_>
 __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                        const bf16raw* __restrict__ dout, const float* __restrict__ lse,
                                                                        const float* __restrict__ delta, bf16raw* __restrict__ dqkv,
@@ -388,21 +450,19 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int s = blockIdx.x, h = blockIdx.y, D = p.H * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  const int nt = NT_ > 0 ? NT_ : (p.L + 31) >> 5, Lp = nt * 32;
   bf16raw* Qs = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Os = Qs + Lp * 64;
   bf16raw* stg = Os + Lp * 64 + wave * MA_STAGE_ELEMS;
   float* Ls = reinterpret_cast<float*>(Os + Lp * 64 + 4 * MA_STAGE_ELEMS);   // lse * log2(e), +huge on padded rows
   float* Ds = Ls + Lp;
-  auto rin = [&](int i) { return m_in_row(p, s, i); };
-  auto rout = [&](int i) { return m_out_row(p, s, i); };
+  const RowLin li = lin_in(p, s), lo = lin_out(p, s);
+  auto rin = [&](int i) { return lin_row(li, i); };
+  auto rout = [&](int i) { return lin_row(lo, i); };
   const int key = wave * 32 + (lane & 31);
   bf16x8 kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    kf[ks] = frag_global(qkv, p.ld_qkv, D + h * 64, key, p.L, ks, lane, rin);
-    vf[ks] = frag_global(qkv, p.ld_qkv, 2 * D + h * 64, key, p.L, ks, lane, rin);
-  }
+  load_row_frags(kf, qkv, p.ld_qkv, D + h * 64, li, key, p.L, lane);
+  load_row_frags(vf, qkv, p.ld_qkv, 2 * D + h * 64, li, key, p.L, lane);
   fill_tiles2(Qs, Os, Lp, p.L, qkv, p.ld_qkv, h * 64, rin, dout, p.ld_dout, h * 64, rout);
   for (int i = threadIdx.x; i < Lp; i += MA_THREADS) {
     const long li = ((long)s * p.H + h) * p.L + i;
@@ -415,14 +475,15 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int kt = wave; kt < nt; kt += 4) {
     bf16x8 kn[4], vn[4];                           // next key tile's fragments, in flight during this one
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kn[ks] = frag_global(qkv, p.ld_qkv, D + h * 64, key + (kt - wave + 4) * 32, p.L, ks, lane, rin);
-      vn[ks] = frag_global(qkv, p.ld_qkv, 2 * D + h * 64, key + (kt - wave + 4) * 32, p.L, ks, lane, rin);
-    }
+    load_row_frags(kn, qkv, p.ld_qkv, D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
+    load_row_frags(vn, qkv, p.ld_qkv, 2 * D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
     f32x16 dk[2], dv[2];
     zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+#pragma unroll(NT_ > 0 ? NT_ : 1)
     for (int qt = 0; qt < nt; ++qt) {
+      // unrolled: keep the instruction scheduler from hoisting the next query tile's fragment reads over this one's tail
+      // (32 more live registers: the kernel sits at the 256-register limit of two waves per SIMD and spilled)
+      if (NT_ > 0) __builtin_amdgcn_sched_barrier(0);
       f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, 0, fo), kf[0], zero, 0, 0, 0);
       f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, 0, fo), vf[0], zero, 0, 0, 0);
 #pragma unroll
@@ -460,7 +521,7 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
     auto base_of = [&](int r) -> bf16raw* {
       const int kk = kt * 32 + r;
       if (kk >= p.L) return nullptr;
-      return (p.mode == VTX_ATTN_SPACE && kk == 0) ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + m_in_row(p, s, kk) * p.ld_dqkv;
+      return (p.mode == VTX_ATTN_SPACE && kk == 0) ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + lin_row(li, kk) * p.ld_dqkv;
     };
     store_rows_T(stg, dk, p.scale, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + D + h * 64 : nullptr; });
     store_rows_T(stg, dv, 1.0f, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + 2 * D + h * 64 : nullptr; });
@@ -732,33 +793,48 @@ int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const 
   return check_launch("attn_bwd_small");
 }
 
-template <typename K>
-static void allow_lds(K kernel, size_t lds) {
-  // > 64 KB of dynamic LDS needs an explicit opt-in (Lp = 256: 64 KB of tiles + 16 KB of staging)
-  if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <auto Kernel>
+static void allow_lds(size_t lds) {
+  // > 64 KB of dynamic LDS needs an explicit opt-in (Lp = 224: 56 KB of tiles + 16 KB of staging), once per kernel
+  // instantiation (the template argument: one static per kernel) and device
+  static std::atomic<unsigned long long> seen{0};
+  if (lds > 65536 && first_launch_on_device(seen))
+    hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
+  const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
+  if (nt == 7) {                                   // L in 193 .. 224: the 197 tokens of every 224^2 / patch 16 model
+    allow_lds<attn_fwd_mfma_kernel<7>>(lds);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel<7>, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv, (bf16raw*)out, lse);
+  } else {
+    allow_lds<attn_fwd_mfma_kernel<0>>(lds);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel<0>, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv, (bf16raw*)out, lse);
+  }
+  return check_launch("attn_fwd_mfma");
+}
+
+template <int NT_>
+static int attn_bwd_mfma_launch_t(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
+                                  float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
   const int Lp = ((p.L + 31) >> 5) * 32;
   const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
-  allow_lds(attn_fwd_mfma_kernel, lds);
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv, (bf16raw*)out, lse);
-  return check_launch("attn_fwd_mfma");
+  allow_lds<attn_bwd_dq_mfma_kernel<NT_>>(lds);
+  allow_lds<attn_bwd_dkv_mfma_kernel<NT_>>(lds + (size_t)2 * Lp * 4);
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<NT_>, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv,
+                     (const bf16raw*)o, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
+  int rc = check_launch("attn_bwd_dq_mfma");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<NT_>, dim3(p.S, p.H), dim3(MA_THREADS), lds + (size_t)2 * Lp * 4, st, p,
+                     (const bf16raw*)qkv, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
+  return check_launch("attn_bwd_dkv_mfma");
 }
 
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
-  const int Lp = ((p.L + 31) >> 5) * 32;
-  const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
-  allow_lds(attn_bwd_dq_mfma_kernel, lds);
-  allow_lds(attn_bwd_dkv_mfma_kernel, lds + (size_t)2 * Lp * 4);
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv,
-                     (const bf16raw*)o, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
-  int rc = check_launch("attn_bwd_dq_mfma");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(p.S, p.H), dim3(MA_THREADS), lds + (size_t)2 * Lp * 4, st, p,
-                     (const bf16raw*)qkv, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
-  return check_launch("attn_bwd_dkv_mfma");
+  if (((p.L + 31) >> 5) == 7) return attn_bwd_mfma_launch_t<7>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+  return attn_bwd_mfma_launch_t<0>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
 }
 
 }  // namespace vtx

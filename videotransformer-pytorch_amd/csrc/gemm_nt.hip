@@ -553,7 +553,11 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   // hooks inside the load sections of P1 .. P4.
   // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section): inside a load
   // section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
-#define PP_KTILE(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_)                                         \
+  // X1_ / X2_ / X4_ (wave-uniform conditions): the wait in P1 / P2 / P4 names a region that was requested BEFORE the NST
+  // result stores of this wave's previous epilogue, so its steady-state count is raised by NST (relaxed first K tiles of a
+  // tile, see `relax` in the continuous flow below)
+#define PP_KTILE(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_) PP_KTILE_X(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, false, false, false)
+#define PP_KTILE_X(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, X1_, X2_, X4_)                        \
     {                                                                                                  \
       const int buf = (kt & 1) ^ par;                                                                  \
       const bool e1 = (E1_), e2 = (E2_);           /* K tile kt+1 / kt+2 exists in this tile */        \
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       /* P1: reads A0, B0; P2 will read B1(kt) */                                                      \
       PP_READ_A(buf, 0);                                                                               \
       PP_READ_B(buf, 1, fb0);                                                                          \
-      if (w1) wait_vmcnt<8>(); else wait_vmcnt<2>();                                                   \
+      if (w1) { if (X1_) wait_vmcnt<8 + NST>(); else wait_vmcnt<8>(); } else wait_vmcnt<2>();          \
       H1_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       PP_BAR();                                                                                        \
       /* P2: reads B1; P3 will read A1(kt) */                                                          \
       PP_READ_B(buf, 2, fb1);                                                                          \
-      if (w1) wait_vmcnt<8>(); else wait_vmcnt<0>();                                                   \
+      if (w1) { if (X2_) wait_vmcnt<8 + NST>(); else wait_vmcnt<8>(); } else wait_vmcnt<0>();          \
       H2_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       PP_MMA(2, 1, fb1, ISS_(1, kt + 2, e2));                                                          \
       PP_BAR();                                                                                        \
       /* P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1) */                           \
-      if (W4_) { if (w2) wait_vmcnt<8>(); else if (w1) wait_vmcnt<4>(); }                              \
+      if (W4_) { if (w2) { if (X4_) wait_vmcnt<8 + NST>(); else wait_vmcnt<8>(); } else if (w1) wait_vmcnt<4>(); } \
       H4_                                                                                              \
       PP_BAR();                                                                                        \
       PP_MMA(2, 0, fb0, ISS_(2, kt + 2, e2));                                                          \
@@ -607,6 +611,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned slot_rd = (unsigned)(unsigned long)(lds_char*)(smem + PP_RING_BYTES);
   const unsigned bias_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 256 + (lane & 31) * 4);
+  // result stores one wave issues per tile when none of its 16 (pass, half-row) groups is empty: one per group, two with a
+  // second output (the activation kernels are only instantiated for the FFN: GELU + GELU', or GELU + pre-activation copy)
+  constexpr int NST = HAS_ACT ? 32 : 16;
+  bool relax = false;                            // continuous operand flow only; set at the end of every epilogue
   int t = next_tile();
   const int tend = xcount;
   if (t >= tend) { check_out(); return; }
@@ -630,7 +638,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
     // younger request in flight (2 DMA instructions per region; issue order A0 B0 B1 A1 per K tile).
     stamp(0);
-    wait_vmcnt<10>();                             // A0(0), B0(0) landed; B1(0) A1(0) A0(1) B0(1) B1(1) in flight
+    // A0(0), B0(0) landed; B1(0) A1(0) A0(1) B0(1) B1(1) -- and, relaxed (see the continuous flow below), the previous
+    // epilogue's stores -- in flight
+    if (relax) wait_vmcnt<10 + NST>(); else wait_vmcnt<10>();
     PP_BAR();
     stamp(1);
     if (wr == 1) PP_BAR();                        // group 1 runs one barrier behind
@@ -661,32 +671,45 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // the wave and reads the result back at once; (b) its wait-count pass treats every LDS-DMA as a FLAT access that
       // may return out of order, so ANY vector-memory result it tracks is waited for with vmcnt(0) while a DMA is in
       // flight -- and here one always is.  So: the atomic and the LDS store of its result are inline asm, both inside
-      // K tile 0 of the main loop (straight-line code between them), and the store sits behind an explicit counted
-      // wait: lane 0's wave issues the bias DMA (0 or 1) + six operand requests between the two, so vmcnt(6) means the
-      // atomic has returned.  `drawn` must not be touched by anything else (checked in the ISA: one def, one use).
+      // K tile 1 of the main loop (straight-line code between them), and the store sits behind an explicit counted
+      // wait: lane 0's wave issues six operand requests between the two, so vmcnt(6) means the atomic has returned.  `drawn` must not be touched by anything else (checked in the ISA: one def, one use).
       int drawn = 0;
       const int one = 1;
       int kt = 0;
       if (more_c) {
-        // every request of every K tile is unconditional here
+        // every request of every K tile is unconditional here.  Draw and hand-over sit in K tile 1 (the other waves read
+        // the word in K tile 2: nk >= 3, the launcher sends shorter K to the per-tile flow).  They used to sit in K tile 0,
+        // where the hand-over's wait made wave 0 wait for the previous tile's result stores as well (vector memory
+        // operations retire in issue order, and the atomic is younger than those stores).
+#define PP_CF_H1 if (kt == 0) bias_dma();                                                                        \
+                 if (kt == 1 && tid == 0)                                                                        \
+                   asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(my_ctr), "v"(one) : "memory");
+#define PP_CF_H2 if (kt == nk - 2) set_tile(t_next, (long)nk * (PP_BK * 2));      /* after P1's A1(nk-1): the last in-tile request */
+#define PP_CF_H3 if (kt == 2) {                                                                                  \
+                   int v;                                                                                        \
+                   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(slot_rd) : "memory"); \
+                   t_nn = __builtin_amdgcn_readfirstlane(v);                                                     \
+                 }
+#define PP_CF_H4 if (kt == 1 && wave == 0) {                                                                     \
+                   wait_vmcnt<6>();                                                                              \
+                   if (tid == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(slot_rd), "v"(drawn) : "memory");     \
+                   lgkm0();                                                                                      \
+                 }
+        // Relaxed first K tiles.  The regions K tiles 0 and 1 of this tile read were requested inside the PREVIOUS main loop,
+        // i.e. before the NST result stores of the previous epilogue; vmcnt counts loads and stores alike and retires
+        // them in issue order, so a wait that names one of those regions only has to leave the stores (and what was
+        // requested since) outstanding: its count grows by NST.  With the steady-state counts every wait of K tile 0 doubled
+        // as a wait for the stores -- 0.5 us per tile for a plain epilogue, 4.7 us for the FFN's two GELU outputs
+        // (profiles/round2_pp_timeline_flows.txt, segment 0-1).  From P2 of K tile 1 on the waited-for regions are younger than
+        // the stores.  `relax` (wave-uniform): this wave's last epilogue issued exactly NST stores.
         for (; kt < nk; ++kt) {
-          PP_KTILE(true, true, true, true, true, PP_ISS_ALWAYS,
-                   if (kt == 0) {
-                     if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(my_ctr), "v"(one) : "memory");
-                     bias_dma();
-                   },
-                   if (kt == nk - 2) set_tile(t_next, (long)nk * (PP_BK * 2));,      /* after P1's A1(nk-1): the last in-tile request */
-                   if (kt == 1) {
-                     int v;
-                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(slot_rd) : "memory");
-                     t_nn = __builtin_amdgcn_readfirstlane(v);
-                   },
-                   if (kt == 0 && wave == 0) {
-                     wait_vmcnt<6>();
-                     if (tid == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(slot_rd), "v"(drawn) : "memory");
-                     lgkm0();
-                   })
+          PP_KTILE_X(true, true, true, true, true, PP_ISS_ALWAYS, PP_CF_H1, PP_CF_H2;, PP_CF_H3, PP_CF_H4,
+                     relax && kt < 2, relax && kt == 0, relax && kt == 0)
         }
+#undef PP_CF_H1
+#undef PP_CF_H2
+#undef PP_CF_H3
+#undef PP_CF_H4
       } else {
         for (; kt < nk; ++kt) {
           PP_KTILE(kt + 1 < nk, kt + 2 < nk, kt + 1 < nk, kt + 2 < nk, true, PP_ISS_COND, if (kt == 0) bias_dma();, , , )
@@ -978,6 +1001,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       if (!more) break;
       if constexpr (CONT) {                         // the next tile's K tiles 0 and 1 are in the ring / on their way
         abase += (long)nk * (PP_BK * 2); bbase += (long)nk * (PP_BK * 2);
+        if constexpr (CF) {
+          // every (pass, half-row) group of this wave had a row inside M and the wave a column inside N: NST stores went
+          // out (rows em0 + 8 g + [0, 8), g = 0 .. 15; a store with an empty execution mask is not issued); the timeline and
+          // the store-free diagnostic mode add or drop vector memory operations
+          const bool second = !HAS_ACT || ep.act == 2 || ep.C2 != nullptr;
+          relax = em0 + 120 < ep.M && en0 < ep.N && second && trace == nullptr && dbg == 0 && nk >= 3;
+        }
         m0 = m0s; n0 = n0s;
         par ^= nk & 1;
         if constexpr (CF) { t = t_next; t_next = t_nn; }
@@ -1024,7 +1054,9 @@ static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st
   const bool sc = d->row_scale != nullptr;
   // continuous flow: row maps that cross a group boundary at most once per 256-row tile (what its 32-bit row
   // offsets assume)
-  const bool cont = cfg.pp_cont != 0 && (d->amap.grp <= 0 || d->amap.grp >= 256);
+  // ... and at least three K tiles: the continuous operand flow draws and hands over the tile index in K tile 1 and reads
+  // it in K tile 2
+  const bool cont = cfg.pp_cont != 0 && (d->amap.grp <= 0 || d->amap.grp >= 256) && d->K / PP_BK >= 3;
   if (d->act) return cont ? launch_pp_t<true, PRE_NONE, false, true, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, true, false>(d, ep, st, cfg);
   if (d->dgelu_in) {
     if (d->dgelu_kind == 1)

@@ -46,31 +46,35 @@ __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
   // loader coordinates: (o = index along the other axis, c = first of 4 elements along the contiguous axis)
   const int ak = A_KCONT ? (tid & 7) * 4 : tid >> 4, ai = A_KCONT ? tid >> 3 : (tid & 15) * 4;
   const int bk = B_KCONT ? (tid & 7) * 4 : tid >> 4, bj = B_KCONT ? tid >> 3 : (tid & 15) * 4;
-  float4 ra, rb;
-  float rx = 0.f;
-  auto gload = [&](int k0) {
+  // Operand tiles are L2-resident but an L2 round trip (~1 us under load) is four times the 8 matrix instructions of a
+  // K tile: three K tiles of register prefetch keep the loop on the matrix pipe instead of on that latency
+  // (one tile of look-ahead measured 45 us per 768^3 product, latency-bound).
+  constexpr int PF = 3;
+  float4 ra[PF], rb[PF];
+  float rx[PF] = {0.f, 0.f, 0.f};
+  auto gload = [&](int k0, float4& va, float4& vb, float& vx) {
     {
       const int i = i0 + ai, k = k0 + ak;
       const bool ok = i < p.N1 && k < p.K;           // extents are multiples of 4: a vector is inside or outside as a whole
       const float* src = p.A + (ok ? (long)i * p.a_rs + (long)k * p.a_ks : 0L);
-      ra = *reinterpret_cast<const float4*>(src);
-      if (!ok) ra = make_float4(0.f, 0.f, 0.f, 0.f);
+      va = *reinterpret_cast<const float4*>(src);
+      if (!ok) va = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     {
       const int j = j0 + bj, k = k0 + bk;
       const bool ok = j < p.N2 && k < p.K;
       const float* src = p.B + (ok ? (long)k * p.b_ks + (long)j * p.b_cs : 0L);
-      rb = *reinterpret_cast<const float4*>(src);
-      if (!ok) rb = make_float4(0.f, 0.f, 0.f, 0.f);
+      vb = *reinterpret_cast<const float4*>(src);
+      if (!ok) vb = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (with_y && tid < WP_BK) rx = (k0 + tid) < p.K ? p.x[k0 + tid] : 0.f;
+    if (with_y && tid < WP_BK) vx = (k0 + tid) < p.K ? p.x[k0 + tid] : 0.f;
   };
-  auto lstore = [&](int buf) {
-    if (A_KCONT) { As[buf][ak][ai] = ra.x; As[buf][ak + 1][ai] = ra.y; As[buf][ak + 2][ai] = ra.z; As[buf][ak + 3][ai] = ra.w; }
-    else { As[buf][ak][ai] = ra.x; As[buf][ak][ai + 1] = ra.y; As[buf][ak][ai + 2] = ra.z; As[buf][ak][ai + 3] = ra.w; }
-    if (B_KCONT) { Bs[buf][bk][bj] = rb.x; Bs[buf][bk + 1][bj] = rb.y; Bs[buf][bk + 2][bj] = rb.z; Bs[buf][bk + 3][bj] = rb.w; }
-    else { Bs[buf][bk][bj] = rb.x; Bs[buf][bk][bj + 1] = rb.y; Bs[buf][bk][bj + 2] = rb.z; Bs[buf][bk][bj + 3] = rb.w; }
-    if (with_y && tid < WP_BK) xs[buf][tid] = rx;
+  auto lstore = [&](int buf, const float4& va, const float4& vb, float vx) {
+    if (A_KCONT) { As[buf][ak][ai] = va.x; As[buf][ak + 1][ai] = va.y; As[buf][ak + 2][ai] = va.z; As[buf][ak + 3][ai] = va.w; }
+    else { As[buf][ak][ai] = va.x; As[buf][ak][ai + 1] = va.y; As[buf][ak][ai + 2] = va.z; As[buf][ak][ai + 3] = va.w; }
+    if (B_KCONT) { Bs[buf][bk][bj] = vb.x; Bs[buf][bk + 1][bj] = vb.y; Bs[buf][bk + 2][bj] = vb.z; Bs[buf][bk + 3][bj] = vb.w; }
+    else { Bs[buf][bk][bj] = vb.x; Bs[buf][bk][bj + 1] = vb.y; Bs[buf][bk][bj + 2] = vb.z; Bs[buf][bk][bj + 3] = vb.w; }
+    if (with_y && tid < WP_BK) xs[buf][tid] = vx;
   };
 
   f32x16 acc;
@@ -79,12 +83,15 @@ __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
   float yacc = 0.f;
   const int fa = qi * 32 + (lane & 31), fb = qj * 32 + (lane & 31), fk = h * 16 + (lane >> 5);
   const int nk = (p.K + WP_BK - 1) / WP_BK;
-  gload(0);
-  lstore(0);
+  // register slot of K tile t = t % PF; LDS buffer = t & 1.  Tile t is consumed while tiles t+1 .. t+PF are in flight.
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (s < nk) gload(s * WP_BK, ra[s], rb[s], rx[s]);
+  lstore(0, ra[0], rb[0], rx[0]);
+  if (PF < nk) gload(PF * WP_BK, ra[0], rb[0], rx[0]);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  auto ktile = [&](int kt, float4& va, float4& vb, float& vx) {   // va/vb/vx: the slot that holds tile kt + 1
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * WP_BK);
 #pragma unroll
     for (int s = 0; s < 8; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][fk + 2 * s][fa], Bs[buf][fk + 2 * s][fb], acc, 0, 0, 0);
@@ -92,8 +99,16 @@ __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
 #pragma unroll
       for (int k = 0; k < WP_BK; ++k) yacc = fmaf(As[buf][k][lane], xs[buf][k], yacc);
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    if (kt + 1 < nk) {
+      lstore(buf ^ 1, va, vb, vx);
+      if (kt + 1 + PF < nk) gload((kt + 1 + PF) * WP_BK, va, vb, vx);   // the slot is free again: tile kt + 1 + PF
+    }
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += PF) {
+    ktile(kt, ra[1], rb[1], rx[1]);
+    if (kt + 1 < nk) ktile(kt + 1, ra[2], rb[2], rx[2]);
+    if (kt + 2 < nk) ktile(kt + 2, ra[0], rb[0], rx[0]);
   }
   // fold the two K halves: waves 4..7 hand their accumulators to waves 0..3 through LDS (the operand tiles are dead)
   float* red = &As[0][0][0];                          // [4][16][64] floats = 16 KB <= sizeof(As)

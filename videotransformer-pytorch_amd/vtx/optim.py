@@ -154,7 +154,10 @@ class FusedSGD(_FusedBase):
     def __init__(self, params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=0.0, clip_grad=None):
         if nesterov and momentum <= 0:
             raise ValueError('Nesterov momentum requires a momentum')
-        super().__init__(params, dict(lr=lr, momentum=momentum, nesterov=nesterov, weight_decay=weight_decay), clip_grad)
+        # the keys torch.optim.SGD keeps in its param_groups ride along unchanged (dampening 0, ...), so that a state dict
+        # saved here loads into torch's class and vice versa
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=nesterov,
+                                      maximize=False, foreach=None, differentiable=False, fused=None), clip_grad)
 
     def _state_tensors(self, p):
         st = self.state[p]
@@ -167,6 +170,8 @@ class FusedSGD(_FusedBase):
         g0 = self.param_groups[0]
         if any(g['momentum'] != g0['momentum'] or g['nesterov'] != g0['nesterov'] for g in self.param_groups):
             raise NotImplementedError('vtx.optim.FusedSGD: momentum / nesterov must be the same in every group')
+        if any(g.get('dampening', 0) or g.get('maximize', False) for g in self.param_groups):
+            raise NotImplementedError('vtx.optim.FusedSGD: dampening / maximize are not implemented')
         _lib.call('vtx_mt_sgd_step', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
                   self._n_chunks, self._norms.data_ptr(), clip, float(g0['momentum']), int(bool(g0['nesterov'])),
                   0, ops.stream())
@@ -176,7 +181,9 @@ class FusedAdamW(_FusedBase):
     """torch.optim.AdamW(lr, betas, eps, weight_decay) as one multi-tensor kernel."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_grad=None):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay), clip_grad)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=True), clip_grad)    # torch.optim.AdamW's keys (see FusedSGD)
 
     def _state_tensors(self, p):
         st = self.state[p]
@@ -189,6 +196,8 @@ class FusedAdamW(_FusedBase):
         g0 = self.param_groups[0]
         if any(g['betas'] != g0['betas'] or g['eps'] != g0['eps'] for g in self.param_groups):
             raise NotImplementedError('vtx.optim.FusedAdamW: betas / eps must be the same in every group')
+        if any(g.get('amsgrad', False) or g.get('maximize', False) or not g.get('decoupled_weight_decay', True) for g in self.param_groups):
+            raise NotImplementedError('vtx.optim.FusedAdamW: amsgrad / maximize / coupled weight decay are not implemented')
         _lib.call('vtx_mt_adamw_step', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
                   self._n_chunks, self._norms.data_ptr(), clip, float(g0['betas'][0]), float(g0['betas'][1]),
                   float(g0['eps']), self._n_steps, ops.stream())
