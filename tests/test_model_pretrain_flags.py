@@ -65,7 +65,9 @@ def test_drop_in_parser_has_every_reference_flag():
     assert args.gpus == [0, 1] and args.mixup is True and args.resume is True      # type=bool: any non-empty string is True
     assert args.min_lr == 1e-6 and args.use_fp16 is True and args.objective == 'mim' and args.synthetic_steps == 0
     assert MP.selected_gpus(args) == [0, 1]
-    tag = MP.experiment_tag(args)
+    tag = MP._reference_tag(args)
+    short = MP.experiment_tag(args)
+    assert len(short.encode()) <= 255 and short.startswith(tag[:200]) and MP.experiment_tag(args) == short
     assert tag.startswith('objective_mim_arch_timesformer_lr_0.001_optim_adamw_lr_schedule_cosine_fp16_True_weight_decay_0.05_')
     assert tag.endswith('frame_interval_4_mixup_True_multi_crop_False_auto_augment_None_')
     with pytest.raises(SystemExit):

@@ -442,7 +442,9 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p
 }
 
 // -------------------------------------------------------------------------- backward: dk, dv
-template <int NT_>
+// VAR_ (tuning variants of the unrolled kernel, option "attn_dkv"): bit 0 = scheduling barrier at every query tile, bit 1 = no
+// prefetch of the wave's next key tile
+template <int NT_, int VAR_>
 __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                        const bf16raw* __restrict__ dout, const float* __restrict__ lse,
                                                                        const float* __restrict__ delta, bf16raw* __restrict__ dqkv,
@@ -475,15 +477,17 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int kt = wave; kt < nt; kt += 4) {
     bf16x8 kn[4], vn[4];                           // next key tile's fragments, in flight during this one
-    load_row_frags(kn, qkv, p.ld_qkv, D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
-    load_row_frags(vn, qkv, p.ld_qkv, 2 * D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
+    if (!(VAR_ & 2)) {
+      load_row_frags(kn, qkv, p.ld_qkv, D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
+      load_row_frags(vn, qkv, p.ld_qkv, 2 * D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
+    }
     f32x16 dk[2], dv[2];
     zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
 #pragma unroll(NT_ > 0 ? NT_ : 1)
     for (int qt = 0; qt < nt; ++qt) {
       // unrolled: keep the instruction scheduler from hoisting the next query tile's fragment reads over this one's tail
       // (32 more live registers: the kernel sits at the 256-register limit of two waves per SIMD and spilled)
-      if (NT_ > 0) __builtin_amdgcn_sched_barrier(0);
+      if (VAR_ & 1) __builtin_amdgcn_sched_barrier(0);
       f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, 0, fo), kf[0], zero, 0, 0, 0);
       f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, 0, fo), vf[0], zero, 0, 0, 0);
 #pragma unroll
@@ -525,8 +529,15 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
     };
     store_rows_T(stg, dk, p.scale, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + D + h * 64 : nullptr; });
     store_rows_T(stg, dv, 1.0f, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + 2 * D + h * 64 : nullptr; });
+    if (VAR_ & 2) {
+      if (kt + 4 < nt) {
+        load_row_frags(kf, qkv, p.ld_qkv, D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
+        load_row_frags(vf, qkv, p.ld_qkv, 2 * D + h * 64, li, key + (kt - wave + 4) * 32, p.L, lane);
+      }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+    }
   }
 }
 
@@ -815,26 +826,34 @@ int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse,
   return check_launch("attn_fwd_mfma");
 }
 
-template <int NT_>
+template <int NT_, int NTK_, int VAR_>
 static int attn_bwd_mfma_launch_t(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                                   float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
   const int Lp = ((p.L + 31) >> 5) * 32;
   const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
   allow_lds<attn_bwd_dq_mfma_kernel<NT_>>(lds);
-  allow_lds<attn_bwd_dkv_mfma_kernel<NT_>>(lds + (size_t)2 * Lp * 4);
+  allow_lds<attn_bwd_dkv_mfma_kernel<NTK_, VAR_>>(lds + (size_t)2 * Lp * 4);
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<NT_>, dim3(p.S, p.H), dim3(MA_THREADS), lds, st, p, (const bf16raw*)qkv,
                      (const bf16raw*)o, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
   int rc = check_launch("attn_bwd_dq_mfma");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<NT_>, dim3(p.S, p.H), dim3(MA_THREADS), lds + (size_t)2 * Lp * 4, st, p,
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<NTK_, VAR_>), dim3(p.S, p.H), dim3(MA_THREADS), lds + (size_t)2 * Lp * 4, st, p,
                      (const bf16raw*)qkv, (const bf16raw*)dout, lse, delta, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
   return check_launch("attn_bwd_dkv_mfma");
 }
 
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
-  if (((p.L + 31) >> 5) == 7) return attn_bwd_mfma_launch_t<7>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
-  return attn_bwd_mfma_launch_t<0>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+  if (((p.L + 31) >> 5) == 7) {
+    switch (options().attn_dkv) {                  // dk / dv kernel: 0 = run-time tile loop, 1..4 = unrolled variants
+      case 1: return attn_bwd_mfma_launch_t<7, 7, 1>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+      case 2: return attn_bwd_mfma_launch_t<7, 7, 0>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+      case 3: return attn_bwd_mfma_launch_t<7, 7, 2>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+      case 4: return attn_bwd_mfma_launch_t<7, 7, 3>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+      default: return attn_bwd_mfma_launch_t<7, 0, 0>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
+    }
+  }
+  return attn_bwd_mfma_launch_t<0, 0, 0>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
 }
 
 }  // namespace vtx

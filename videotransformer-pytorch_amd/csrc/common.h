@@ -168,6 +168,8 @@ struct Options {
   int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
   int attn_hw_fwd = 16;      // VTX_ATTN_HW_FWD / _BWD: short-sequence attention with n heads of a row tile in one workgroup
   int attn_hw_bwd = 0;       //   (0: one head per workgroup, four row tiles)
+  int attn_dkv = 3;          // VTX_ATTN_DKV: dk / dv kernel of the 197-token attention: 0 = run-time query-tile loop, 1..4 = unrolled variants
+                             // (3 = unrolled, next key tile loaded behind the current one: profiles/round3_attn_dkv_variants.txt)
   int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
   int pp_cg = 0;             // VTX_GEMM_PP_CG: column tiles per group (0: from K)
   int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing); 2 / 3 = diagnostics: no stores / no staging

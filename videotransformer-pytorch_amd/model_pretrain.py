@@ -94,7 +94,18 @@ def parse_args(argv=None):
 
 
 def experiment_tag(args):
-    """The results directory name of the reference (model_pretrain.py:168-176)."""
+    """The results directory name of the reference (model_pretrain.py:168-176).  The reference's string is ~300 characters
+    long -- longer than the 255-byte file-name limit of ext4 / xfs / overlayfs, where its ``os.makedirs`` raises
+    ``OSError: File name too long`` -- so a tag over the limit is cut to its first 200 characters + '_' + 12 hex digits of
+    its SHA-1 (still one directory per flag combination, still recognisable)."""
+    tag = _reference_tag(args)
+    if len(tag.encode()) > 255:
+        import hashlib
+        tag = tag[:200] + '_' + hashlib.sha1(tag.encode()).hexdigest()[:12]
+    return tag
+
+
+def _reference_tag(args):
     return (f'objective_{args.objective}_arch_{args.arch}_lr_{args.lr}_'
             f'optim_{args.optim_type}_lr_schedule_{args.lr_schedule}_'
             f'fp16_{args.use_fp16}_weight_decay_{args.weight_decay}_'

@@ -54,12 +54,15 @@ class GradBuckets:
         self._launched = []
 
     def _close(self, plist):
-        n = sum(p.numel() for p in plist)
+        # every gradient view starts on a 16-byte boundary (the kernels that write gradients in place take 16-byte vectors):
+        # a parameter whose element count is not a multiple of 4 (a 10-class head bias) is followed by a few unused floats
+        pad4 = lambda n: (n + 3) // 4 * 4               # noqa: E731
+        n = sum(pad4(p.numel()) for p in plist)
         flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
         off = 0
         for p in plist:
             p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            off += pad4(p.numel())
         self.buckets.append(dict(params=plist, flat=flat, pending=len(plist), handle=None, comm=None))
 
     def _make_hook(self, bi):
