@@ -23,7 +23,7 @@
  *     both modes (bias, LayerNorm gamma/beta, all gradients of parameters) are
  *     typed float* here.
  *   - "row map": a logical row m of an operand lives at physical row
- *         base + m + (m / grp) * skip
+ *         base + m + (m / grp) * skip            (or base + m + tab[m / grp], see vtx_rowmap)
  *     which expresses "skip the cls row of every clip" (grp = P*T, skip = 1,
  *     base = 1) and "one row per clip" (grp = 1, skip = P*T) without copies.
  *     grp <= 0 means identity (+ base).
@@ -49,8 +49,13 @@ extern "C" {
 
 typedef struct {
   int grp;   /* rows per group (<=0: no groups) */
-  int skip;  /* extra physical rows at the start of every group */
+  int skip;  /* extra physical rows at the start of every group (table form: an upper bound of tab[g + 1] - tab[g]) */
   int base;  /* physical row of logical row 0 */
+  const int* tab; /* NULL, or a DEVICE array of one row offset per group (non-decreasing) + one spare entry: the table form
+                        base + m + tab[m / grp]
+                     -- "the kept clips only" of a DropPath'ed FFN (transformer.py:34-42,543: group g = the g-th kept clip,
+                     tab[g] = (its clip index - g) * rows per clip).  Accepted by LayerNorm, the element-wise kernels and
+                     the C / residual maps of vtx_gemm_nt; vtx_gemm_nt's A map and vtx_gemm_tn take the closed form only. */
 } vtx_rowmap;
 
 int vtx_version(void);

@@ -286,6 +286,53 @@ def test_direct_parameter_gradients_match_autograd_accumulation():
             functions.set_direct_grads(False)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,rows_per,D,Hd', [(5, 37, 128, 256), (6, 1569, 768, 3072)])
+def test_ffn_skips_dropped_clips(dtype, B, rows_per, D, Hd):
+    """DropPath at the FFN drops whole clips (reference transformer.py:34-42,543).  FFNFn runs the block on the kept clips
+    only -- table row maps in LayerNorm, the fc2 epilogue's residual / result rows and the gradient gather (the large case
+    goes through the persistent GEMM's residual-block flow) -- and must give what computing every clip and multiplying by
+    zero gives: the same stream values bit for bit, the same input gradient, parameter gradients up to the fp32 summation
+    order of the weight-gradient reduction."""
+    from vtx import functions as F_
+    g = torch.Generator().manual_seed(11)
+    r = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc)              # noqa: E731
+    x0 = r(B, rows_per, D).to(dtype)
+    dout = r(B, rows_per, D).to(dtype)
+    params0 = [1 + 0.1 * r(D), 0.1 * r(D), r(Hd, D, sc=D ** -0.5), 0.1 * r(Hd), r(D, Hd, sc=Hd ** -0.5), 0.1 * r(D)]
+    c = float(np.float32(1.0) / np.float32(0.9))
+    patterns = [[1, 3], [0], [B - 1], list(range(B)), list(range(1, B)), []]
+    for dropped in patterns:
+        host = torch.tensor([0.0 if i in dropped else c for i in range(B)], dtype=torch.float32)
+        res = []
+        for compact in (False, True, True):               # the compact path twice: it must be deterministic
+            F_.set_compact_droppath(compact)
+            try:
+                x = x0.to(DEV).requires_grad_(True)
+                ps = [p.clone().to(DEV).requires_grad_(True) for p in params0]
+                sv = host.to(DEV)
+                sv._vtx_host = host
+                y = F_.FFNFn.apply(x, *ps, sv, 1e-5)
+                y.backward(dout.to(DEV))
+                torch.cuda.synchronize()
+                res.append((y.detach().cpu(), x.grad.cpu(), [p.grad.cpu() for p in ps]))
+            finally:
+                F_.set_compact_droppath(True)
+        (y0, dx0, g0), (y1, dx1, g1), (y2, dx2, g2) = res
+        tag = f'ffn compaction {dtype} B={B} rows={rows_per} dropped={dropped}'
+        assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and all(torch.equal(a, b) for a, b in zip(g1, g2)), tag + ': not deterministic'
+        assert torch.equal(y0, y1), tag + ': outputs differ'
+        assert torch.equal(dx0[dropped], dx1[dropped]) and torch.equal(y1[dropped], x0[dropped]), tag
+        if len(dropped) < B:
+            # (bf16: single-ulp differences of small elements were seen at full size, 3e-5 of max|dx|)
+            check(tag + ' dx', dx1.float(), dx0.float(), 1e-6 if dtype == torch.float32 else 1e-4)
+        for name, a, b in zip(('ln_w', 'ln_b', 'w1', 'b1', 'w2', 'b2'), g1, g0):
+            if len(dropped) == B:
+                assert torch.count_nonzero(a) == 0 and torch.count_nonzero(b) == 0, tag
+            else:
+                check(f'{tag} d{name}', a, b, 2e-5)
+
+
 def test_batch_and_length_properties():
     """Size-independent properties at full width: clips are independent (a clip's output does not
     depend on its batch neighbours) and eval forward is deterministic."""

@@ -41,6 +41,28 @@ def _compile(src, force):
     return obj, True
 
 
+def build_variant(name, defines):
+    """An experimental build next to the product library: libvtx_<name>.so with -D<defines> (objects under _obj/<name>/);
+    load it with VTX_LIB=<path> to A/B two builds on the same GPU box (tools/micro/*.sh).  Not part of build()."""
+    obj_dir = os.path.join(OBJ, name)
+    os.makedirs(obj_dir, exist_ok=True)
+    out = os.path.join(PKG, f'libvtx_{name}.so')
+
+    def one(src):
+        obj = os.path.join(obj_dir, src.replace('.hip', '.o'))
+        cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ['-D' + d for d in defines] + ['-c', os.path.join(HERE, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr}')
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(one, SOURCES))
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr}')
+    return out
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
@@ -59,4 +81,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--variant' in sys.argv:                         # python build.py --variant NAME DEFINE[=VALUE] ...
+        i = sys.argv.index('--variant')
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force='--force' in sys.argv)

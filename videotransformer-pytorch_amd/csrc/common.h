@@ -92,10 +92,14 @@ __device__ inline void store8_nt(bf16raw* p, const float (&v)[8]) {
 // Row indices fit 32 bits: use a 32-bit unsigned division (a 64-bit one costs ~100 instructions
 // and this sits in GEMM loaders / epilogues).
 __host__ __device__ inline long map_row(const vtx_rowmap& m, long r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (m.tab != nullptr) return (long)m.base + r + (long)m.tab[(unsigned)r / (unsigned)m.grp];     // table form (grp > 0)
+#endif
   const long q = (m.grp > 0) ? (long)((unsigned)r / (unsigned)m.grp) * (long)m.skip : 0;
   return (long)m.base + r + q;
 }
-inline vtx_rowmap ident_map() { vtx_rowmap m; m.grp = 0; m.skip = 0; m.base = 0; return m; }
+inline vtx_rowmap ident_map() { vtx_rowmap m; m.grp = 0; m.skip = 0; m.base = 0; m.tab = nullptr; return m; }
+inline bool closed_form(const vtx_rowmap& m) { return m.tab == nullptr; }
 
 // ---- wave reductions (wave = 64) ---------------------------------------------
 __device__ inline float wave_sum(float v) {

@@ -47,10 +47,25 @@ __device__ inline TileMap make_tile_map(const vtx_rowmap& m, int first_row) {
   const unsigned q0 = m.grp > 0 ? (unsigned)first_row / (unsigned)m.grp : 0u;
   t.base_q = (long)m.base + (long)q0 * (long)m.skip;
   t.bound = m.grp > 0 ? (int)((q0 + 1) * (unsigned)m.grp) : 0x7fffffff;
+  if (m.tab != nullptr) {                        // table form: the offsets of the tile's first group and of the one behind it
+    // (the entry behind the last group is never applied -- no row of the tile lies beyond `bound` then -- but is read:
+    // the table carries one spare entry)
+    // (first_row is wave-uniform; the explicit readfirstlane keeps the offsets in scalar registers: the persistent GEMM
+    // builds scalar base addresses from them)
+    const int o0 = __builtin_amdgcn_readfirstlane(m.tab[q0]), o1 = __builtin_amdgcn_readfirstlane(m.tab[q0 + 1]);
+    t.base_q = (long)m.base + o0;
+    t.skip = o1 - o0;
+  }
   return t;
 }
 __device__ inline long tile_map_row(const TileMap& t, const vtx_rowmap& m, int r) {     // r in [first_row, first_row + 256)
   if (t.fast) return t.base_q + r + (r >= t.bound ? (long)t.skip : 0L);
+  return map_row(m, r);
+}
+// the same for a WAVE-UNIFORM row whose result feeds a scalar base address (a table offset comes out of a vector load)
+__device__ inline long tile_map_row_u(const TileMap& t, const vtx_rowmap& m, int r) {
+  if (t.fast) return t.base_q + r + (r >= t.bound ? (long)t.skip : 0L);
+  if (m.tab != nullptr) return (long)m.base + r + (long)__builtin_amdgcn_readfirstlane(m.tab[(unsigned)r / (unsigned)m.grp]);
   return map_row(m, r);
 }
 

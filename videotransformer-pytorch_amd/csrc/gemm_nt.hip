@@ -394,6 +394,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     long long* __restrict__ trace, int dbg, EpiParams ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
+  amap.tab = nullptr;                            // the A map is in closed form (vtx_gemm_nt checks it): no table code below
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -552,7 +553,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   // One 64-deep K tile = four phases.  ISS_: what the request slots of the four MFMA sections issue; H1_ .. H4_:
   // hooks inside the load sections of P1 .. P4.
   // The LDS-DMA requests are issued in the shadow of the MFMAs (after the first two of a section): inside a load
-  // section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.
+  // section each costs the wave 100+ cycles on the critical path, among MFMAs ~60.  (Round 3, same box A/B of three
+  // builds that issued P2's and / or P4's request in that phase's load section instead -- 4 and 0 fragment reads there
+  // -- behind the section's wait, i.e. at the same place of the request order: +0.5 / +0.8 / +1.1 % over the twelve GEMMs
+  // of a layer, profiles/round3_nt_variants.txt.  The weight-gradient kernel, whose sections are longer, gains from it.)
+#ifndef VTX_PP_BF16_STAGE
+#define VTX_PP_BF16_STAGE 1          // packed row-pair staging of the plain epilogue (see PAIRS below); 0 = fp32 staging
+#endif
   // X1_ / X2_ / X4_ (wave-uniform conditions): the wait in P1 / P2 / P4 names a region that was requested BEFORE the NST
   // result stores of this wave's previous epilogue, so its steady-state count is raised by NST (relaxed first K tiles of a
   // tile, see `relax` in the continuous flow below)
@@ -673,7 +680,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // flight -- and here one always is.  So: the atomic and the LDS store of its result are inline asm, both inside
       // K tile 1 of the main loop (straight-line code between them), and the store sits behind an explicit counted
       // wait: lane 0's wave issues six operand requests between the two, so vmcnt(6) means the atomic has returned.  `drawn` must not be touched by anything else (checked in the ISA: one def, one use).
-      int drawn = 0;
+      int drawn;                                   // deliberately NOT initialised: with `= 0` hipcc shares the register with a
+                                                   // zero it keeps for 64-bit address arithmetic (seen in the ISA: v_mad_u64_u32
+                                                   // reading the pair between the atomic and its hand-over)
+      asm volatile("" : "=v"(drawn));              // an opaque definition for the paths that never draw
       const int one = 1;
       int kt = 0;
       if (more_c) {
@@ -736,10 +746,10 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       const int lastv = min(ep.M - 1, (pres && ep.split_row > 0) ? ep.split_row - 1 : 0x7fffffff);
       const int m0c = min(m0, lastv);              // a tile of split rows only: everything reads row `lastv`
       const TileMap prm = make_tile_map(ep.rmap, m0c);
-      const long pfirst = pres ? tile_map_row(prm, ep.rmap, m0c) : (long)m0c;
+      const long pfirst = pres ? tile_map_row_u(prm, ep.rmap, m0c) : (long)m0c;
       const char* pbase = reinterpret_cast<const char*>(pres ? ep.R : ep.dgelu_in) + pfirst * (long)pld2;
       const int pbl = (pres && ep.rmap.grp > 0) ? prm.bound - m0c : 0x7fffffff;         // local row at which the skip starts
-      const int pskip = pres ? ep.rmap.skip : 0;
+      const int pskip = pres ? prm.skip : 0;       // (the tile's own step in the table form)
       const int plast = lastv - m0c;               // >= 0
       const int pl0 = (m0 - m0c) + wr * 128 + (lane >> 3);
       auto pre_piece = [&](int j, bf16raw* dst) {  // rows 8j .. 8j+7 of the block: lane -> row 8j + lane/8, chunk lane%8
@@ -988,8 +998,62 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           if ((p_) < 7 && more) issue((p_) & 3, nk + ((p_) >> 2));                                      \
         }                                                                                               \
       }
-      PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
-      PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
+      // Plain epilogue (nothing to read, no activation, no row scale: result = bf16(acc + bias)): the pass stages PAIRS OF
+      // ROWS as packed bf16 -- registers 2k, 2k+1 of an accumulator are the same column of two adjacent rows, so one
+      // v_cvt_pk_bf16_f32 + one ds_write_b32 stage two elements -- instead of fp32 words: 8 LDS writes and 2 LDS reads
+      // per lane and pass instead of 16 and 4 (the fp32 staging moved 512 KB through the LDS per tile, ~2.3 us of the
+      // 4.7 us the eight passes of a plain tile take, most of it on the 64-B-per-clock ds_write_b32 path).  A lane then
+      // holds rows 2p, 2p+1 (p = lane / 8) of 8 columns as 8 words {row 2p | row 2p+1}: eight v_perm_b32 separate them.
+      // Row-pair r sits at word r * 64 + 4 * ((r >> 1) & 1) + 8 * (r >> 2): the 4-word shift keeps the 16-lane groups of the
+      // ds_read_b128 on 64 distinct banks, the 8-word one keeps row-pair 3's shifted tail off row-pair 4.  Same value, same rounding (one fp32 add, one round-to-nearest-even) as the fp32 staging.
+      constexpr bool PAIRS = VTX_PP_BF16_STAGE && PRE == PRE_NONE && !HAS_SC && !HAS_ACT;
+      if constexpr (PAIRS) {
+        unsigned* const stgw = reinterpret_cast<unsigned*>(stg);
+        const int p2 = lane >> 3;
+        const unsigned pair_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) +
+                                                                       (p2 * 64 + 4 * ((p2 >> 1) & 1) + 8 * (p2 >> 2) + (lane & 7) * 8) * 4);
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define PP_EPI2B(p_, mi_, half_)                                                                        \
+        {                                                                                               \
+          const int col = lane & 31, hi = lane >> 5;                                                    \
+          _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int k = 0; k < 4; ++k) { \
+            /* registers 2k, 2k+1 of this half: rows {0,2,8,10}[k] + 4 hi (+1) of the pass's 16 */     \
+            const int rp = ((2 * k) & 3) / 2 + 4 * ((2 * k) >> 2) + 2 * hi;                             \
+            union { bf16x2 v; unsigned u; } w;                                                          \
+            w.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 2 * k] + bcol[ni]);                            \
+            w.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 2 * k + 1] + bcol[ni]);                        \
+            stgw[rp * 64 + 4 * ((rp >> 1) & 1) + 8 * (rp >> 2) + ni * 32 + col] = w.u;                  \
+          }                                                                                             \
+          lgkm0();                                                                                      \
+          __builtin_amdgcn_wave_barrier();                                                              \
+          u32x4 w0, w1;                                                                                 \
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"  \
+                       : "=&v"(w0), "=&v"(w1) : "v"(pair_rd) : "memory");                               \
+          __builtin_amdgcn_sched_barrier(0);                                                            \
+          _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                               \
+            const unsigned sel = u ? 0x07060302u : 0x05040100u;    /* high / low halves of (second, first) */ \
+            u32x4 o;                                                                                    \
+            o[0] = __builtin_amdgcn_perm(w0[1], w0[0], sel);                                            \
+            o[1] = __builtin_amdgcn_perm(w0[3], w0[2], sel);                                            \
+            o[2] = __builtin_amdgcn_perm(w1[1], w1[0], sel);                                            \
+            o[3] = __builtin_amdgcn_perm(w1[3], w1[2], sel);                                            \
+            const int m = em0 + 16 * (p_) + 2 * p2 + u;                                                 \
+            const bool ok = col_ok && m < ep.M && dbg != 2;                                             \
+            const bool split = ep.split_row > 0 && m >= ep.split_row;                                   \
+            if (ok) {                                                                                   \
+              if (split) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16raw*>(ep.Csplit) + (long)(m - ep.split_row) * ep.ldsplit + en) = o; \
+              else __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<bf16raw*>(ep.C) + tile_map_row(cm, ep.cmap, m) * ep.ldc + en)); \
+            }                                                                                           \
+          }                                                                                             \
+          __builtin_amdgcn_wave_barrier();                                                              \
+        }
+        PP_EPI2B(0, 0, 0) PP_EPI2B(1, 0, 1) PP_EPI2B(2, 1, 0) PP_EPI2B(3, 1, 1)
+        PP_EPI2B(4, 2, 0) PP_EPI2B(5, 2, 1) PP_EPI2B(6, 3, 0) PP_EPI2B(7, 3, 1)
+#undef PP_EPI2B
+      } else {
+        PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
+        PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
+      }
 #undef PP_EPI2
       stamp(6);
       if constexpr (HAS_PRE && !PF) {
@@ -1203,6 +1267,9 @@ extern "C" int vtx_gemm_nt(const vtx_gemm_desc* d, void* stream) {
               "gemm_nt: split_row needs an aligned Csplit");
   VTX_REQUIRE(!d->row_scale || (d->rs_d1 > 0 && d->rs_d2 > 0), VTX_EINVAL, "gemm_nt: row_scale divisors must be > 0");
   VTX_REQUIRE(d->act >= 0 && d->act <= 2, VTX_EINVAL, "gemm_nt: bad act %d", d->act);
+  VTX_REQUIRE(closed_form(d->amap), VTX_EINVAL, "gemm_nt: the A row map must be in closed form (no table)");
+  VTX_REQUIRE((closed_form(d->cmap) || d->cmap.grp > 0) && (closed_form(d->rmap) || d->rmap.grp > 0), VTX_EINVAL,
+              "gemm_nt: a table row map needs grp > 0");
 
   EpiParams ep;
   ep.M = d->M; ep.N = d->N;

@@ -1096,6 +1096,7 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
   VTX_REQUIRE(d->N1 % 8 == 0 && d->N2 % 8 == 0, VTX_EINVAL, "gemm_tn: N1=%d, N2=%d must be multiples of 8", d->N1, d->N2);
   VTX_REQUIRE(d->A && d->B && d->C && d->workspace, VTX_EINVAL, "gemm_tn: null pointer");
   VTX_REQUIRE(d->ldc == d->N2, VTX_EINVAL, "gemm_tn: C must be contiguous (ldc == N2)");
+  VTX_REQUIRE(closed_form(d->amap) && closed_form(d->bmap), VTX_EINVAL, "gemm_tn: row maps must be in closed form (no table)");
   VTX_REQUIRE(d->dtype == VTX_F32 || d->dtype == VTX_BF16, VTX_EINVAL, "gemm_tn: bad dtype");
   const long vec = d->dtype == VTX_BF16 ? 8 : 4;
   VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C) && aligned16(d->workspace) &&

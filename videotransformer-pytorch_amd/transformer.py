@@ -82,7 +82,9 @@ class DropPath(nn.Module):
         if device.type != 'cuda':
             return scale
         # no hipMemcpy: a copy kernel reads the mask from pinned host memory (see vtx.ops.upload_f32)
-        return vtx.ops.upload_f32(scale, device)
+        dev = vtx.ops.upload_f32(scale, device)
+        dev._vtx_host = scale                                # the host copy: lets the FFN skip the dropped clips' rows
+        return dev
 
     def forward(self, x):
         s = self.scale_vector(x.shape[0], x.ndim, x.device)

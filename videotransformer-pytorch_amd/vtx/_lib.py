@@ -17,10 +17,10 @@ ATTN_CONTIG, ATTN_SPACE = 0, 1
 
 
 class RowMap(C.Structure):
-    _fields_ = [('grp', C.c_int), ('skip', C.c_int), ('base', C.c_int)]
+    _fields_ = [('grp', C.c_int), ('skip', C.c_int), ('base', C.c_int), ('tab', C.c_void_p)]
 
 
-IDENT = RowMap(0, 0, 0)
+IDENT = RowMap(0, 0, 0, None)
 
 
 class GemmDesc(C.Structure):

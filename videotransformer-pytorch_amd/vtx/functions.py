@@ -482,6 +482,57 @@ class SelfAttnFn(torch.autograd.Function):
         return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None)
 
 
+_compact = True
+
+
+def set_compact_droppath(on):
+    """FFNFn: skip the rows of the clips DropPath drops (default) or compute every clip and multiply by zero."""
+    global _compact
+    _compact = bool(on)
+
+
+def _compaction_plan(scale_vec, n_units, rows_per, device):
+    """DropPath at the FFN drops whole clips (reference transformer.py:34-42: one draw per sample, :543 p up to 0.1): their
+    LayerNorm, both GEMMs and all of their backward are multiplied by zero.  With the mask's host copy at hand (the draw
+    happens on the CPU generator, as in the reference) the block runs on the KEPT clips only: logical row m of the compact
+    problem is row m + tab[m // rows_per] of the stream (table row map, include/vtx.h).  -> None when nothing is dropped, else
+    (kept count, dropped count, largest step of the keep / drop tables, device buffer [keep table | drop table | scales of
+    the kept clips]); _plan_maps() turns the buffer into row maps."""
+    host = getattr(scale_vec, '_vtx_host', None) if scale_vec is not None else None
+    if not _compact or host is None or host.numel() != n_units:
+        return None
+    hv = host.numpy()
+    kept = [i for i in range(n_units) if hv[i] != 0.0]
+    drop = [i for i in range(n_units) if hv[i] == 0.0]
+    if not drop:
+        return None
+    def table(idx):                                  # one offset per group + the spare entry the tile maps read
+        t = [(c - j) * rows_per for j, c in enumerate(idx)]
+        return t + [t[-1] if t else 0]
+    tk, td = table(kept), table(drop)
+    import numpy as np
+    words = np.concatenate([np.asarray(tk, np.int32).view(np.float32), np.asarray(td, np.int32).view(np.float32),
+                            np.asarray([hv[i] for i in kept], np.float32)])
+    buf = ops.upload_f32(torch.from_numpy(words), device)
+    ik = buf[:len(tk)].view(torch.int32)
+    idr = buf[len(tk):len(tk) + len(td)].view(torch.int32)
+    sv_k = buf[len(tk) + len(td):]
+    step = lambda t: max([b - a for a, b in zip(t, t[1:])] + [0])      # noqa: E731
+    return len(kept), len(drop), step(tk), step(td), buf
+
+
+def _plan_maps(plan, rows_per):
+    """(keep map, drop map, per-kept-clip scales) over the plan's device buffer.  Built from the buffer at hand, never
+    kept across forward / backward: under activation recomputation (torch.utils.checkpoint) backward receives the
+    RE-COMPUTED buffer, and a row map stored by the first forward would point into freed memory."""
+    nk, nd, step_k, step_d, buf = plan
+    ik = buf[:nk + 1].view(torch.int32)
+    idr = buf[nk + 1:nk + nd + 2].view(torch.int32)
+    sv_k = buf[nk + nd + 2:]
+    kmap = ops.tabmap(rows_per, ik, step_k) if nk else None
+    return kmap, ops.tabmap(rows_per, idr, step_d), sv_k
+
+
 class FFNFn(torch.autograd.Function):
     """FFNWithPreNorm.forward with num_layers == 2 (reference transformer.py:516-523)."""
 
@@ -493,6 +544,9 @@ class FFNFn(torch.autograd.Function):
         rows_per = M // x.shape[0]
         Hd = w1.shape[0]
         dtp = x.dtype
+        plan = _compaction_plan(scale_vec, x.shape[0], rows_per, x.device)
+        if plan is not None:
+            return FFNFn._forward_compact(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, plan, rows_per)
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
@@ -515,7 +569,75 @@ class FFNFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _forward_compact(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, plan, rows_per):
+        """The kept clips only (see _compaction_plan); the dropped clips leave the block as they came in."""
+        nk, nd, step_k, step_d, buf = plan
+        kmap, dmap, sv_k = _plan_maps(plan, rows_per)
+        D = x.shape[-1]
+        Hd = w1.shape[0]
+        dtp = x.dtype
+        Mk = nk * rows_per
+        out = torch.empty_like(x)
+        need_t = any(ctx.needs_input_grad)
+        w1c, w1T = weights(w1, dtp, need_t)
+        w2c, w2T = weights(w2, dtp, need_t)
+        if nk > 0:
+            xn = _empty((Mk, D), x)
+            mean = _empty((Mk,), x, torch.float32)
+            rstd = _empty((Mk,), x, torch.float32)
+            ops.layernorm_fwd(x, Mk, D, D, kmap, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+            h = _empty((Mk, Hd), x)
+            g = _empty((Mk, Hd), x)
+            ops.gemm_nt(xn, w1c, g, Mk, Hd, D, bias=b1, act=2, C2=h)
+            ops.gemm_nt(g, w2c, out, Mk, D, Hd, cmap=kmap, bias=b2, row_scale=sv_k, rs=(rows_per, 1, 1, 0), R=x, rmap=kmap)
+        else:
+            xn = mean = rstd = h = g = x.new_empty(0)
+        ops.row_scale_copy(x, out, nd * rows_per, D, smap=dmap, dmap=dmap)
+        ctx.save_for_backward(x, ln_w, mean, rstd, xn, h, g, buf, *[t for t in (w1T, w2T) if t is not None])
+        ctx.cfg = (rows_per, True, Hd)
+        ctx.plan = (nk, nd, step_k, step_d)
+        ctx.params = (ln_w, ln_b, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def _backward_compact(ctx, dout):
+        x, ln_w, mean, rstd, xn, h, g, buf, w1T, w2T = ctx.saved_tensors
+        p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2 = ctx.params
+        rows_per, _, Hd = ctx.cfg
+        nk, nd = ctx.plan[:2]
+        kmap, dmap, sv_k = _plan_maps(ctx.plan + (buf,), rows_per)
+        dout = _chk(dout)
+        D = x.shape[-1]
+        Mk = nk * rows_per
+        dx = torch.empty_like(x)
+        d_ln_w = d_ln_b = d_w1 = d_b1 = d_w2 = d_b2 = None
+        if nk > 0:
+            dz = _empty((Mk, D), x)
+            ops.row_scale_copy(dout, dz, Mk, D, smap=kmap, s=sv_k, rs=(rows_per, 1, 1, 0))
+            d_w2, d_b2 = _linear_grads(p_w2, p_b2, dz, g, Mk, D, Hd)
+            dh = _empty((Mk, Hd), x)
+            ops.gemm_nt(dz, w2T, dh, Mk, Hd, D, dgelu_in=h, dgelu_kind=1)
+            d_w1, d_b1 = _linear_grads(p_w1, p_b1, dh, xn, Mk, Hd, D)
+            dxn = _empty((Mk, D), x)
+            ops.gemm_nt(dh, w1T, dxn, Mk, D, Hd)
+            d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
+            ops.layernorm_bwd(dxn, D, IDENT, x, D, kmap, Mk, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+            if direct:
+                _fire(p_ln_w, p_ln_b)
+                d_ln_w = d_ln_b = None
+        else:                                        # every clip dropped: the parameters get no gradient from this block
+            for p in (p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2):
+                if _sink(p) is not None:
+                    _fire(p)
+            zeros = [None if _sink(p) is not None else torch.zeros_like(p) for p in (p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2)]
+            d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2 = zeros
+        ops.row_scale_copy(dout, dx, nd * rows_per, D, smap=dmap, dmap=dmap)
+        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None)
+
+    @staticmethod
     def backward(ctx, dout):
+        if getattr(ctx, 'plan', None) is not None:
+            return FFNFn._backward_compact(ctx, dout)
         x, ln_w, mean, rstd, xn, h, g, sv, w1T, w2T = ctx.saved_tensors
         p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2 = ctx.params
         rows_per, has_scale, Hd = ctx.cfg

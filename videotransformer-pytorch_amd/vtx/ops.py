@@ -49,6 +49,22 @@ def rowmap(grp=0, skip=0, base=0):
     return RowMap(int(grp), int(skip), int(base))
 
 
+def tabmap(rows_per_group, table, max_step):
+    """Table row map: logical row m -> m + table[m // rows_per_group] (``table``: int32 device tensor, one row offset per
+    group plus a spare entry; ``max_step``: upper bound of the difference of two consecutive entries)."""
+    need_cuda(table)
+    if table.dtype != torch.int32:
+        raise TypeError('tabmap: int32 table expected')
+    return RowMap(int(rows_per_group), int(max_step), 0, table.data_ptr())
+
+
+def upload_i32(values, device):
+    """list / array of ints -> int32 device tensor, through the pinned-memory copy kernel of upload_f32 (bit copy)."""
+    import numpy as np
+    a = np.asarray(values, dtype=np.int32)
+    return upload_f32(torch.from_numpy(a.view(np.float32)), device).view(torch.int32)
+
+
 def tokmap(n_tokens):
     """logical token row (clip-major, no cls) -> physical row of a [B, 1+N, D] tensor."""
     return RowMap(int(n_tokens), 1, 1)
