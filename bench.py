@@ -39,6 +39,7 @@ import torch.distributed as dist  # noqa: E402
 FLOPS_FWD_BWD_PER_CLIP = {8: 1.175e12, 16: 2.352e12, 2: 0.2937e12}
 PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0         # TB/s (spec; ~6.3 TB/s is what a streaming copy reaches)
+PMC_ROUNDS = ('round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
 
 
 def parse():
@@ -122,8 +123,8 @@ def cpu_baseline(frames, steps=3, budget_s=60.0):
 
 
 def pmc_traffic_per_launch(B, args):
-    """HBM-side bytes per vtx_gemm_nt launch from the committed rocprofv3 PMC passes of THIS command
-    (profiles/round2_pmc_{FETCH,WRITE}_SIZE_b<B>.txt: separate --pmc passes, KB per dispatch summed over
+    """HBM-side bytes per vtx_gemm_nt launch REPLAYED from the committed rocprofv3 PMC passes of THIS command
+    (profiles/round<N>_pmc_{FETCH,WRITE}_SIZE_b<B>.txt: separate --pmc passes, KB per dispatch summed over
     the listed dispatches).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced
     streams on gfx950; WRITE_SIZE is uncalibrated and taken as is.  None when no committed pass matches
     the configuration (the counters cannot be collected from inside the timed run)."""
@@ -131,10 +132,11 @@ def pmc_traffic_per_launch(B, args):
         return None
     here = os.path.dirname(os.path.abspath(__file__))
     tot = 0.0
-    for name, mult in ((f'round2_pmc_FETCH_SIZE_b{B}.txt', 2.0), (f'round2_pmc_WRITE_SIZE_b{B}.txt', 1.0)):
+    for name, mult in ((f'pmc_FETCH_SIZE_b{B}.txt', 2.0), (f'pmc_WRITE_SIZE_b{B}.txt', 1.0)):
         try:
             kb, rows = 0.0, 0.0
-            for line in open(os.path.join(here, 'profiles', name)):
+            path = next(pth for pth in (os.path.join(here, 'profiles', r + name) for r in PMC_ROUNDS) if os.path.isfile(pth))
+            for line in open(path):
                 if 'nt_bf16_pp_kernel' in line:            # one line per template instantiation (names are cut on the left): pool them
                     f = dict(kv.split('=') for kv in line.split() if '=' in kv)
                     kb += float(f['total'])
@@ -142,7 +144,7 @@ def pmc_traffic_per_launch(B, args):
             if rows <= 0:
                 return None
             tot += mult * kb * 1024.0 / rows
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             return None
     return round(tot, 0) if tot > 0 else None
 
@@ -280,10 +282,10 @@ def main():
     # ---- instrumented pass (outside the timed region): every kernel class, HIP events per launch ----
     classes = None
     if not args.no_breakdown and rank == 0:
-        names = ('gemm_nt', 'gemm_tn', 'attn_fwd_time', 'attn_bwd_time', 'attn_fwd_space', 'attn_bwd_space', 'ln_fwd', 'ln_bwd',
+        names = ('gemm_nt', 'gemm_tn', 'wprod', 'attn_fwd_time', 'attn_bwd_time', 'attn_fwd_space', 'attn_bwd_space', 'ln_fwd', 'ln_bwd',
                  'colsum', 'patch_rows', 'hog')
         nb = 2
-        frames_u8 = torch.randint(0, 256, (64, 224, 224, 3), dtype=torch.uint8, device=dev)   # MaskFeat HOG targets
+        frames_u8 = torch.randint(0, 256, (1024, 224, 224, 3), dtype=torch.uint8, device=dev)   # MaskFeat HOG targets of 64 clips
         ops.hog_fwd(frames_u8)                          # builds / uploads the magnitude table once
         ops.profile_start(names)
         torch.cuda.synchronize()
@@ -320,15 +322,20 @@ def main():
                        if (world > 1 or force_dp) else 'none'},
             'clips_per_sec_per_gpu': round(value / world, 3),
             'model_tflops_per_gpu': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12, 2),
-            'mfma_frac_whole_step': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12 / PEAK_BF16, 4),
-            'model_flops_note': 'model_tflops / mfma_frac_whole_step price the NOMINAL FLOPs of the reference graph (BASELINE.md '
-                                'section 3); the merged attn.proj + temporal_fc GEMM (DESIGN.md 4.4) executes 5.7 % fewer at 8 frames. '
-                                'roofline.* counts executed FLOPs only.',
+            'mfma_frac_whole_step_nominal': round(value / world * FLOPS_FWD_BWD_PER_CLIP.get(args.frames, 0) / 1e12 / PEAK_BF16, 4),
+            'model_flops_note': 'model_tflops / mfma_frac_whole_step_nominal price the NOMINAL FLOPs of the reference graph (BASELINE.md '
+                                'section 3); mfma_frac_whole_step prices the FLOPs the step EXECUTES (matrix products of every '
+                                'vtx_gemm_nt / vtx_gemm_tn / vtx_wprod / attention launch of one instrumented step: the merged attn.proj + '
+                                'temporal_fc GEMM (DESIGN.md 4.4) and the clips DropPath drops at the FFN (4.5) are not computed) over the '
+                                'timed ms_per_step. roofline.* counts executed FLOPs only.',
             'final_loss': round(final_loss, 4),
             'roofline': {'kernel': 'gemm_nt_bf16_pp_kernel (all vtx_gemm_nt launches)' if args.precision == 'bf16' else 'gemm_nt_f32_kernel',
                          'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4),
-                         'traffic': pmc_traffic_per_launch(B, args), 'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
+                         'traffic': pmc_traffic_per_launch(B, args),
+                         'traffic_source': 'replayed: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command under profiles/ '
+                                           '(2 x FETCH_SIZE + WRITE_SIZE per launch), not counted in this run',
+                         'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
                          'flops_per_launch_avg': round(flops / max(n, 1), 0),
                          'algorithmic_bytes_per_launch_avg': round(nbytes / max(n, 1), 0)},
         }
@@ -340,6 +347,10 @@ def main():
             for k in ('nt', 'tn'):
                 for r in out['gemm_shapes'][k]:
                     r['launches_per_step'] = r.pop('launches') // nb
+            mm = ('gemm_nt', 'gemm_tn', 'wprod', 'attn_fwd_time', 'attn_bwd_time', 'attn_fwd_space', 'attn_bwd_space')
+            executed = sum(tot[c][2] for c in mm if c in tot) / nb
+            out['executed_matrix_tflop_per_step'] = round(executed / 1e12, 3)
+            out['mfma_frac_whole_step'] = round(executed / (elapsed / args.steps) / 1e12 / peak, 4)
             out['gemm_tn_roofline'] = {'achieved': round(tot['gemm_tn'][2] / (tot['gemm_tn'][1] * 1e-3) / 1e12, 2), 'peak': peak,
                                        'unit': 'TFLOP/s', 'frac': round(tot['gemm_tn'][2] / (tot['gemm_tn'][1] * 1e-3) / 1e12 / peak, 4),
                                        'ms_per_step': round(tot['gemm_tn'][1] / nb, 3)}
@@ -347,7 +358,7 @@ def main():
             label = {'ln_fwd': 'ln_fwd_kernel', 'ln_bwd': 'ln_bwd_kernel', 'attn_fwd_time': 'attn_fwd_small_kernel (temporal, T tokens)',
                      'attn_bwd_time': 'attn_bwd_small_kernel (temporal)', 'attn_fwd_space': 'attn_fwd_mfma_kernel (spatial, 197 tokens)',
                      'attn_bwd_space': 'attn_bwd_*_mfma_kernel (spatial)', 'patch_rows': 'patch_rows_kernel (clip gather)',
-                     'colsum': 'colsum_kernel', 'hog': 'hog_kernel (64 frames 224x224x3 uint8 -> float64 features)'}
+                     'colsum': 'colsum_kernel', 'hog': 'hog_kernel (1024 frames 224x224x3 uint8 -> float64 features)'}
             for c, (cn, cms, cfl, cby) in tot.items():
                 if c in label and cn:
                     a = cby / (cms * 1e-3) / 1e12

@@ -324,8 +324,12 @@ def test_ffn_skips_dropped_clips(dtype, B, rows_per, D, Hd):
         assert torch.equal(y0, y1), tag + ': outputs differ'
         assert torch.equal(dx0[dropped], dx1[dropped]) and torch.equal(y1[dropped], x0[dropped]), tag
         if len(dropped) < B:
-            # (bf16: single-ulp differences of small elements were seen at full size, 3e-5 of max|dx|)
-            check(tag + ' dx', dx1.float(), dx0.float(), 1e-6 if dtype == torch.float32 else 1e-4)
+            # bf16: every intermediate (LayerNorm output and statistics, both GEMMs, dh, dxn) is bit-identical between the
+            # two paths (tools/micro/ffn_compact_debug.py); the LayerNorm backward kernel handles two rows per trip in two
+            # inlined copies of its row code whose fp32 contraction differs in the last bit, and which copy a row gets depends
+            # on the row count -- a handful of elements per tensor land on the other side of a bf16 rounding boundary
+            check(tag + ' dx', dx1.float(), dx0.float(), 1e-6 if dtype == torch.float32 else 4e-3)
+            assert (dx1 != dx0).sum().item() <= max(4, dx0.numel() // 100000), tag + ': too many elements of dx differ'
         for name, a, b in zip(('ln_w', 'ln_b', 'w1', 'b1', 'w2', 'b2'), g1, g0):
             if len(dropped) == B:
                 assert torch.count_nonzero(a) == 0 and torch.count_nonzero(b) == 0, tag

@@ -16,7 +16,7 @@ import torch
 import __graft_entry__ as ge
 ge.ensure_built()
 import vtx
-from vtx import ops
+from vtx import ops, functions as F_
 import transformer as T
 import video_transformer as V
 
@@ -41,7 +41,7 @@ def train(name, model, batch, frames, flops_per_clip, steps=6, warmup=2, recompu
 
     def step():
         buckets.zero()
-        loss = torch.nn.functional.cross_entropy(head(m(x)), y)
+        loss = F_.SoftmaxXentFn.apply(head(m(x)), y)
         loss.backward()
         buckets.finish()
         opt.step()
@@ -78,7 +78,7 @@ def timesformer_b16(batch=48):
     train('TimeSformer-B divided_space_time, 16x3x224x224, bf16, fwd+CE+bwd+SGD', V.TimeSformer(num_frames=16), batch, 16, 2.352e12)
 
 
-def timesformer_l96(batch=4):
+def timesformer_l96(batch=4, recompute=True):
     """BASELINE cfg 4: TimeSformer-L (D 1024, 16 heads, 24 layers), 96 frames: 18 817 tokens per clip.  Per-block
     recompute keeps one block's activations (2.1 GB per clip) instead of 24.  FLOPs per clip fwd+bwd (recompute not
     counted): 6 * tokens * 12 D^2 * 24 layers for the Linears + attention cores."""
@@ -87,12 +87,13 @@ def timesformer_l96(batch=4):
     # per layer Linears: temporal qkv (3 D^2) + proj (D^2) + temporal_fc (D^2) + spatial qkv (3 D^2) + proj (D^2) + FFN (8 D^2) = 17 D^2
     lin = 6.0 * tokens * (17 * D * D) * layers
     attn = 3.0 * layers * (4.0 * tokens * 96 * D + 4.0 * tokens * 197 * D)     # fwd 4 L hd per token and head, x3 for fwd+bwd
-    train('TimeSformer-L divided_space_time (D 1024, 24 layers), 96x3x224x224, bf16, fwd+CE+bwd+SGD, per-block recompute (BASELINE cfg 4)',
+    train('TimeSformer-L divided_space_time (D 1024, 24 layers), 96x3x224x224, bf16, fwd+CE+bwd+SGD, '
+          + ('per-block recompute' if recompute else 'all activations stored (2.1 GB per layer and clip)') + ' (BASELINE cfg 5)',
           V.TimeSformer(num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=24), batch, 96,
-          lin + attn, steps=3, warmup=1, recompute=True)
+          lin + attn, steps=3, warmup=1, recompute=recompute)
 
 
-def hog(frames_n=256, iters=20):
+def hog(frames_n=1024, iters=10):
     frames = torch.randint(0, 256, (frames_n, 224, 224, 3), dtype=torch.uint8, device=DEV)
     for _ in range(3):
         ops.hog_fwd(frames)
@@ -134,3 +135,7 @@ if __name__ == '__main__':
         timesformer_b16()
     if 'tsfl96' in which:
         timesformer_l96()
+    if 'tsfl96_stored' in which:                      # 4 clips with every activation stored: ~205 GB of the 288
+        timesformer_l96(batch=4, recompute=False)
+    if 'tsfl96_12' in which:
+        timesformer_l96(batch=12)

@@ -8,7 +8,7 @@ for db in glob.glob(sys.argv[1] + '/**/*.db', recursive=True):
     kn = 'kernel_name' if 'kernel_name' in cols else 'name'
     acc = collections.defaultdict(lambda: [0.0, 0])
     for name, cn, v in c.execute(f"select {kn}, counter_name, value from {view}"):
-        if 'gemm' not in name and 'attn' not in name:
+        if not any(k in name for k in ('gemm', 'attn', 'ln_', 'wprod')):
             continue
         a = acc[(name.split('(')[0][-48:], cn)]
         a[0] += v; a[1] += 1
