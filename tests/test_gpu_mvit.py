@@ -79,7 +79,8 @@ def test_maxpool_skip(dtype, thw):
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('hd,heads,Lq,Lk', [(96, 2, 130, 37), (96, 1, 300, 393), (64, 3, 33, 200)])
+@pytest.mark.parametrize('hd,heads,Lq,Lk', [(96, 2, 130, 37), (96, 1, 300, 393), (64, 3, 33, 200), (96, 2, 2500, 393), (96, 4, 1569, 128),
+                                           (64, 2, 700, 161)])
 def test_cross_attention(dtype, hd, heads, Lq, Lk):
     from vtx import functions as F_
     B, C = 2, heads * hd
@@ -97,6 +98,22 @@ def test_cross_attention(dtype, hd, heads, Lq, Lk):
     check(f'{tag} out', o.float().cpu(), ref.detach(), TOL[dtype])
     for name, a, b in zip('qkv', g, ref_in):
         check(f'{tag} d{name}', a.grad.float().cpu(), b.grad, 2 * TOL[dtype])
+    if dtype == torch.bfloat16:                      # the MFMA kernels (xattn_mfma.hip): deterministic, and equal to the VALU ones
+        import vtx                                   # of mvit.hip within bf16 rounding
+        g2 = [t.to(DEV).to(dtype).requires_grad_(True) for t in (qq, kk, vv)]
+        o2 = F_.XAttnFn.apply(g2[0], g2[1], g2[2], heads)
+        o2.backward(do.to(DEV).to(dtype))
+        assert torch.equal(o2, o) and all(torch.equal(a.grad, b.grad) for a, b in zip(g, g2)), tag + ': not deterministic'
+        vtx.set_option('attn_valu', 1)
+        try:
+            g3 = [t.to(DEV).to(dtype).requires_grad_(True) for t in (qq, kk, vv)]
+            o3 = F_.XAttnFn.apply(g3[0], g3[1], g3[2], heads)
+            o3.backward(do.to(DEV).to(dtype))
+        finally:
+            vtx.set_option('attn_valu', 0)
+        check(f'{tag} out mfma vs valu', o.float().cpu(), o3.float().cpu(), TOL[dtype])
+        for name, a, b in zip('qkv', g, g3):
+            check(f'{tag} d{name} mfma vs valu', a.grad.float().cpu(), b.grad.float().cpu(), 2 * TOL[dtype])
 
 
 @pytest.mark.parametrize('dtype', DT)

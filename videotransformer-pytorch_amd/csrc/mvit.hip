@@ -8,7 +8,8 @@
 //                  (heads interleaved in the feature axis): the conv weight of column c is w[c % hd].
 //   maxpool_skip   MaxPool3d(kernel (1,3,3), stride (1,2,2), padding (0,1,1)) on the residual path, cls kept.
 //   xattn          softmax(q k^T hd^-0.5) v with Lq != Lk (queries and keys pooled by different strides),
-//                  head_dim 96 (MViT-B) or 64; fp32 VALU arithmetic, K/V tiles in LDS, online softmax.
+//                  head_dim 96 (MViT-B) or 64.  bf16: the MFMA kernels of xattn_mfma.hip; fp32 (and option attn_valu):
+//                  the VALU kernels below (K/V tiles in LDS, online softmax).
 //   pos_encoding   separable spatial + temporal position embedding and the cls token.
 //   im2col3d       rows of the overlapping Conv3d(3 -> 96, kernel (3,7,7), stride (2,4,4), padding (1,3,3)) stem.
 //
@@ -677,6 +678,16 @@ extern "C" int vtx_im2col3d(int dtype, int B, int T, int C, int H, int W, const 
   return check_launch("im2col3d");
 }
 
+// xattn_mfma.hip: the bf16 MFMA kernels (head_dim 96 / 64)
+namespace vtx {
+bool xattn_mfma_eligible(int dtype, int hd);
+int xattn_mfma_splits(int B, int Lq, int Lk, int heads);
+int xattn_fwd_mfma_launch(const vtx_xattn_desc* d, hipStream_t st);
+int xattn_bwd_mfma_launch(const vtx_xattn_desc* d, const void* dout, float* delta, void* dq, int nsplit, float* part_k, float* part_v,
+                          long part_stride, hipStream_t st);
+}
+static bool xattn_use_mfma(const vtx_xattn_desc* d) { return xattn_mfma_eligible(d->dtype, d->hd) && !options().attn_valu; }
+
 static int xattn_check(const vtx_xattn_desc* d, const char* who) {
   VTX_REQUIRE(d != nullptr, VTX_EINVAL, "%s: null descriptor", who);
   VTX_REQUIRE(d->dtype == VTX_F32 || d->dtype == VTX_BF16, VTX_EINVAL, "%s: bad dtype", who);
@@ -691,6 +702,7 @@ extern "C" int vtx_xattn_fwd(const vtx_xattn_desc* d, void* stream) {
   if (rc) return rc;
   dim3 g(cdiv(d->Lq, XA_THREADS), d->heads, d->B), blk(XA_THREADS);
   hipStream_t st = as_stream(stream);
+  if (xattn_use_mfma(d)) return xattn_fwd_mfma_launch(d, st);
 #define L_(T_, HD_) hipLaunchKernelGGL((xattn_fwd_kernel<T_, HD_>), g, blk, 0, st, d->Lq, d->Lk, d->heads, d->scale, (const T_*)d->q, (const T_*)d->k, \
                                        (const T_*)d->v, (T_*)d->out, d->lse)
   MV_DISPATCH(d->dtype, d->hd, L_(float, 96), L_(bf16raw, 96), L_(float, 64), L_(bf16raw, 64), "xattn_fwd");
@@ -710,6 +722,8 @@ static int xattn_splits(const vtx_xattn_desc* d) {
 
 extern "C" size_t vtx_xattn_bwd_workspace(const vtx_xattn_desc* d) {
   if (!d) return 0;
+  if (xattn_use_mfma(d))                        // the MFMA dk / dv kernel always leaves fp32 partials
+    return (size_t)2 * xattn_mfma_splits(d->B, d->Lq, d->Lk, d->heads) * d->B * d->Lk * d->heads * d->hd * sizeof(float);
   const int s = xattn_splits(d);
   return s > 1 ? (size_t)2 * s * d->B * d->Lk * d->heads * d->hd * sizeof(float) : 16;
 }
@@ -721,6 +735,18 @@ extern "C" int vtx_xattn_bwd(const vtx_xattn_desc* d, const void* dout, float* d
   VTX_REQUIRE(dout && delta && dq && dk && dv && workspace, VTX_EINVAL, "xattn_bwd: null pointer");
   VTX_REQUIRE(ws_bytes >= vtx_xattn_bwd_workspace(d), VTX_EWS, "xattn_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
+  if (xattn_use_mfma(d)) {
+    const int ns = xattn_mfma_splits(d->B, d->Lq, d->Lk, d->heads);
+    const long stride = (long)d->B * d->Lk * d->heads * d->hd;
+    float* pk = (float*)workspace;
+    float* pv = pk + (size_t)ns * stride;
+    rc = xattn_bwd_mfma_launch(d, dout, delta, dq, ns, pk, pv, stride, st);
+    if (rc) return rc;
+    const long n8 = stride / 8;
+    hipLaunchKernelGGL(xattn_reduce_kernel<bf16raw>, dim3(grid_for(n8)), dim3(256), 0, st, pk, ns, stride, n8, (bf16raw*)dk);
+    hipLaunchKernelGGL(xattn_reduce_kernel<bf16raw>, dim3(grid_for(n8)), dim3(256), 0, st, pv, ns, stride, n8, (bf16raw*)dv);
+    return check_launch("xattn_reduce");
+  }
   const int kblocks = cdiv(d->Lk, XA_THREADS), nsplit = xattn_splits(d);
   const int q_per = cdiv(cdiv(d->Lq, nsplit), XA_TILE) * XA_TILE;
   const long part_stride = (long)d->B * d->Lk * d->heads * d->hd;
