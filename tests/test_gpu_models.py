@@ -329,7 +329,8 @@ def test_ffn_skips_dropped_clips(dtype, B, rows_per, D, Hd):
             # inlined copies of its row code whose fp32 contraction differs in the last bit, and which copy a row gets depends
             # on the row count -- a handful of elements per tensor land on the other side of a bf16 rounding boundary
             check(tag + ' dx', dx1.float(), dx0.float(), 1e-6 if dtype == torch.float32 else 4e-3)
-            assert (dx1 != dx0).sum().item() <= max(4, dx0.numel() // 100000), tag + ': too many elements of dx differ'
+            if dtype == torch.bfloat16:                  # (fp32: that last bit is visible in a few per cent of the elements)
+                assert (dx1 != dx0).sum().item() <= max(4, dx0.numel() // 100000), tag + ': too many elements of dx differ'
         for name, a, b in zip(('ln_w', 'ln_b', 'w1', 'b1', 'w2', 'b2'), g1, g0):
             if len(dropped) == B:
                 assert torch.count_nonzero(a) == 0 and torch.count_nonzero(b) == 0, tag
