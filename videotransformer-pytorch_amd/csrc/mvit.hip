@@ -19,71 +19,84 @@
 namespace vtx {
 
 // ---------------------------------------------------------------------------------------------------
-// pool_conv_ln.  Half a wave (32 lanes) owns one (output token, head): lane l holds columns l, l+32, ... of the head.
+// pool_conv_ln.  A group of LPU lanes owns one (output token, head); lane l < hd/8 of the group holds channels
+// 8l .. 8l+7 of the head (one 16-byte load per tap; hd 96 leaves 4 of 16 lanes idle).  Conv weights in LDS as [tap][channel].
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void pool_conv_ln_fwd_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw, int heads,
                                                                const T* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                T* __restrict__ pre, T* __restrict__ y, float* __restrict__ mean,
                                                                float* __restrict__ rstd) {
-  constexpr int CPL = HD / 32;
+  constexpr int LPU = HD == 96 ? 16 : 8, UPB = 256 / LPU;
+  __shared__ float s_w[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) s_w[i] = w[(i % HD) * 27 + i / HD];
+  __syncthreads();
   const int C = heads * HD;
-  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
-  const long unit = (long)blockIdx.x * 8 + (threadIdx.x >> 5);          // (b, out token, head)
-  const int l = threadIdx.x & 31;
-  if (unit >= (long)B * n_out * heads) return;
-  const int hd_i = (int)(unit % heads);
-  const long bo = unit / heads;
-  const long o = bo % n_out;
-  const int b = (int)(bo / n_out);
-  const T* xb = x + (long)b * n_in * C + hd_i * HD;
-  float v[CPL];
-  if (o == 0) {
+  const unsigned HoWo = (unsigned)Ho * Wo;
+  const unsigned n_in = 1 + (unsigned)Tn * H * W, n_out = 1 + (unsigned)Tn * HoWo;
+  const unsigned units = (unsigned)B * n_out * heads;                     // < 2^31 (checked by the launcher)
+  const unsigned unit = blockIdx.x * UPB + threadIdx.x / LPU;             // (b, out token, head)
+  const int l = threadIdx.x % LPU;
+  const bool act = l < HD / 8 && unit < units;
+  const unsigned bo = unit / heads, hd_i = unit - bo * heads;
+  const unsigned b = bo / n_out, o = bo - b * n_out;
+  const int c0 = (int)hd_i * HD + l * 8;
+  float v[8];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) v[j] = ET<T>::ld(xb + l + 32 * j);
-  } else {
-    const long r = o - 1;
-    const int to = (int)(r / ((long)Ho * Wo)), ho = (int)((r / Wo) % Ho), wo = (int)(r % Wo);
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  const long orow = ((long)b * n_out + o) * C + c0;
+  if (act) {
+    const T* xb = x + (long)b * n_in * C + c0;
+    if (o == 0) {
+      load8(xb, v);
+    } else {
+      const unsigned r = o - 1;
+      const unsigned to = r / HoWo, rr = r - to * HoWo, ho = rr / (unsigned)Wo, wo = rr - ho * Wo;
+      for (int kt = 0; kt < 3; ++kt) {
+        const int t = (int)to + kt - 1;
+        if (t < 0 || t >= Tn) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hh = (int)ho * sh + kh - 1;
+          if (hh < 0 || hh >= H) continue;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) v[j] = 0.f;
-    for (int kt = 0; kt < 3; ++kt) {
-      const int t = to + kt - 1;
-      if (t < 0 || t >= Tn) continue;
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hh = ho * sh + kh - 1;
-        if (hh < 0 || hh >= H) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ww = wo * sw + kw - 1;
-          if (ww < 0 || ww >= W) continue;
-          const T* xr = xb + (1 + ((long)t * H + hh) * W + ww) * C;
-          const int tap = (kt * 3 + kh) * 3 + kw;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ww = (int)wo * sw + kw - 1;
+            if (ww < 0 || ww >= W) continue;
+            float xv[8];
+            load8(xb + (1 + ((long)t * H + hh) * W + ww) * C, xv);
+            const float* wt = s_w + ((kt * 3 + kh) * 3 + kw) * HD + l * 8;
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) v[j] = fmaf(w[(l + 32 * j) * 27 + tap], ET<T>::ld(xr + l + 32 * j), v[j]);
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(wt[j], xv[j], v[j]);
+          }
         }
       }
     }
+    store8(pre + orow, v);
+    load8(pre + orow, v);                       // the LayerNorm sees the stored (rounded) value, as backward will
   }
-  T* pr = pre + ((long)b * n_out + o) * C + hd_i * HD;
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) {
-    ET<T>::st(pr + l + 32 * j, v[j]);
-    v[j] = ET<T>::ld(pr + l + 32 * j);          // the LayerNorm sees the stored (rounded) value, as backward will
-    s += v[j];
-  }
+  for (int j = 0; j < 8; ++j) s += v[j];
 #pragma unroll
-  for (int m = 16; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+  for (int m = LPU / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
   const float mu = s / HD;
   float q = 0.f;
+  if (act) {
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) { const float d = v[j] - mu; q += d * d; }
+    for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; q += d * d; }
+  }
 #pragma unroll
-  for (int m = 16; m > 0; m >>= 1) q += __shfl_xor(q, m, 64);
+  for (int m = LPU / 2; m > 0; m >>= 1) q += __shfl_xor(q, m, 64);
   const float rs = rsqrtf(q / HD + eps);
-  T* yr = y + ((long)b * n_out + o) * C + hd_i * HD;
+  if (act) {
+    float g8[8], b8[8];
+    load8(gamma + l * 8, g8);
+    load8(beta + l * 8, b8);
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) ET<T>::st(yr + l + 32 * j, (v[j] - mu) * rs * gamma[l + 32 * j] + beta[l + 32 * j]);
-  if (l == 0) { mean[unit] = mu; rstd[unit] = rs; }
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu) * rs * g8[j] + b8[j];
+    store8(y + orow, v);
+    if (l == 0) { mean[unit] = mu; rstd[unit] = rs; }
+  }
 }
 
 // LayerNorm backward per (token, head): dpre, and per-block partial sums of dgamma / dbeta
@@ -126,97 +139,132 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(long units, int heads,
   }
 }
 
-// dx of the depthwise conv (gather over the outputs whose window holds the input token); cls row passes through
+// dx of the depthwise conv (gather over the outputs whose window holds the input token); cls row passes through.
+// One block per (clip, t, h) row of the input grid (+ one per clip for the cls row): which kt / kh taps reach an output
+// is block-uniform, only the kw test is per thread.  A thread owns 8 consecutive channels of one token of the row
+// (one 16-byte load per live tap); the conv weights sit in LDS as [tap][channel].  Tap order (kt, kh, kw) is fixed.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void pool_conv_bwd_data_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw, int C,
                                                                  const T* __restrict__ dpre, const float* __restrict__ w,
                                                                  T* __restrict__ dx) {
+  __shared__ float s_w[27 * HD];
+  const int rows = Tn * H + 1;
+  const int b = blockIdx.x / rows, row = blockIdx.x - b * rows;
   const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
-  const long total = (long)B * n_in * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long bn = i / C;
-    const long n = bn % n_in;
-    const int b = (int)(bn / n_in);
-    const T* db = dpre + (long)b * n_out * C + c;
-    float a = 0.f;
-    if (n == 0) {
-      a = ET<T>::ld(db);
-    } else {
-      const long r = n - 1;
-      const int t = (int)(r / ((long)H * W)), h = (int)((r / W) % H), ww = (int)(r % W);
-      const float* wc = w + (c % HD) * 27;
-      for (int kt = 0; kt < 3; ++kt) {
-        const int to = t - kt + 1;
-        if (to < 0 || to >= Tn) continue;
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hn = h - kh + 1;
-          if (hn < 0 || hn % sh || hn / sh >= Ho) continue;
-          for (int kw = 0; kw < 3; ++kw) {
-            const int wn = ww - kw + 1;
-            if (wn < 0 || wn % sw || wn / sw >= Wo) continue;
-            a = fmaf(wc[(kt * 3 + kh) * 3 + kw], ET<T>::ld(db + (1 + ((long)to * Ho + hn / sh) * Wo + wn / sw) * C), a);
-          }
+  const int C8 = C / 8;
+  const T* db = dpre + (long)b * n_out * C;
+  T* dxb = dx + (long)b * n_in * C;
+  float a[8];
+  if (row == rows - 1) {                                  // cls
+    for (int i = threadIdx.x; i < C8; i += 256) { load8(db + i * 8, a); store8(dxb + i * 8, a); }
+    return;
+  }
+  const int t = row / H, h = row - t * H;
+  int hq[3];                                              // output row reached through tap kh, or -1
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hn = h - kh + 1, q = hn >= 0 ? hn / sh : -1;
+    hq[kh] = (q >= 0 && q * sh == hn && q < Ho) ? q : -1;
+  }
+  T* dxr = dxb + (1 + (long)row * W) * C;
+  const int items = W * C8;
+  if ((hq[0] & hq[1] & hq[2]) < 0) {                      // no output row looks at this input row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int i = threadIdx.x; i < items; i += 256) store8(dxr + (long)i * 8, a);
+    return;
+  }
+  for (int i = threadIdx.x; i < 27 * HD; i += 256) s_w[i] = w[(i % HD) * 27 + i / HD];
+  __syncthreads();
+  for (int i = threadIdx.x; i < items; i += 256) {
+    const int ww = i / C8, c0 = (i - ww * C8) * 8;
+    const float* wc = s_w + c0 % HD;
+    int wq[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wn = ww - kw + 1, q = wn >= 0 ? wn / sw : -1;
+      wq[kw] = (q >= 0 && q * sw == wn && q < Wo) ? q : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int to = t - kt + 1;
+      if (to < 0 || to >= Tn) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        if (hq[kh] < 0) continue;
+        const T* dr = db + (1 + ((long)to * Ho + hq[kh]) * Wo) * C + c0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          if (wq[kw] < 0) continue;
+          float v[8];
+          load8(dr + (long)wq[kw] * C, v);
+          const float* wt = wc + ((kt * 3 + kh) * 3 + kw) * HD;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] = fmaf(wt[j], v[j], a[j]);
         }
       }
     }
-    ET<T>::st(dx + i, a);
+    store8(dxr + (long)i * 8, a);
   }
 }
 
-// dW[c][tap] partials: each block covers a slice of (b, output token) pairs.  256 / HD thread groups split the slice;
-// a thread owns one channel of the head being processed, so every LDS slot has one writer and the fold over heads and
-// groups runs in a fixed order (deterministic).
+// dW[c][tap] partials: each block covers a slice of (b, output token) pairs.  A thread owns one tap of one 8-channel
+// chunk of the head (32 lanes per chunk, 27 of them live): per pair it reads the chunk of dpre and the chunk of x at
+// its tap's position (two 16-byte loads) for 8 multiply-adds.  The pairs' rows and grid positions are worked out once
+// per batch of PB pairs into LDS.  One accumulator set per thread, summed over heads and pairs in a fixed order.
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void pool_conv_bwd_weight_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw, int heads,
-                                                                   const T* __restrict__ dpre, const T* __restrict__ x,
-                                                                   float* __restrict__ part) {
-  constexpr int NG = 256 / HD;
-  __shared__ float red[NG][27 * HD];
+__global__ __launch_bounds__((HD / 8) * 32) void pool_conv_bwd_weight_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int sh, int sw,
+                                                                             int heads, const T* __restrict__ dpre,
+                                                                             const T* __restrict__ x, float* __restrict__ part) {
+  constexpr int PB = 64;
+  __shared__ int4 s_pair[PB];      // {dpre row, x row of the window's corner (may lie off the grid), t+1 | (h+1)<<8 | (w+1)<<20 of it, -}
   const int C = heads * HD;
-  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
-  const long pairs = (long)B * (n_out - 1);
+  const unsigned HoWo = (unsigned)Ho * Wo;
+  const unsigned n_in = 1 + (unsigned)Tn * H * W, per_clip = (unsigned)Tn * HoWo, n_out = 1 + per_clip;
+  const long pairs = (long)B * per_clip;
   const long per = (pairs + gridDim.x - 1) / gridDim.x;
   const long p0 = (long)blockIdx.x * per, p1 = min(pairs, p0 + per);
-  const int grp = threadIdx.x / HD, ch = threadIdx.x % HD;
-  const bool worker = grp < NG;
-  float tot[27];
+  const int tap = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+  const bool live = tap < 27;
+  const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+  const int tap_off = (kt * H + kh) * W + kw;
+  float acc[8];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) tot[k] = 0.f;
-  if (worker) {
-    for (int hh = 0; hh < heads; ++hh) {
-      const int c = hh * HD + ch;
-      for (long p = p0 + grp; p < p1; p += NG) {
-        const int b = (int)(p / (n_out - 1));
-        const long r = p % (n_out - 1);
-        const int to = (int)(r / ((long)Ho * Wo)), ho = (int)((r / Wo) % Ho), wo = (int)(r % Wo);
-        const float d = ET<T>::ld(dpre + ((long)b * n_out + 1 + r) * C + c);
-        const T* xb = x + (long)b * n_in * C + c;
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (long q0 = p0; q0 < p1; q0 += PB) {
+    const int nb = (int)min((long)PB, p1 - q0);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const unsigned p = (unsigned)(q0 + threadIdx.x);
+      const unsigned b = p / per_clip, r = p - b * per_clip;
+      const unsigned to = r / HoWo, rr = r - to * HoWo, ho = rr / (unsigned)Wo, wo = rr - ho * Wo;
+      const int t0 = (int)to - 1, h0 = (int)(ho * sh) - 1, w0 = (int)(wo * sw) - 1;
+      s_pair[threadIdx.x] = make_int4((int)(b * n_out + 1 + r), (int)(b * n_in) + 1 + (t0 * H + h0) * W + w0,
+                                      (t0 + 1) | ((h0 + 1) << 8) | ((w0 + 1) << 20), 0);
+    }
+    __syncthreads();
+    if (live) {
+      for (int hh = 0; hh < heads; ++hh) {
+        const int c0 = hh * HD + chunk * 8;
+        for (int i = 0; i < nb; ++i) {
+          const int4 pr = s_pair[i];
+          const int t = (pr.z & 255) - 1 + kt, h = ((pr.z >> 8) & 4095) - 1 + kh, ww = (int)((unsigned)pr.z >> 20) - 1 + kw;
+          if ((unsigned)t < (unsigned)Tn && (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W) {
+            float d8[8], x8[8];
+            load8(dpre + (long)pr.x * C + c0, d8);
+            load8(x + (long)(pr.y + tap_off) * C + c0, x8);
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt) {
-          const int t = to + kt - 1;
-#pragma unroll
-          for (int kh = 0; kh < 3; ++kh) {
-            const int hh2 = ho * sh + kh - 1;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              const int ww = wo * sw + kw - 1;
-              if (t >= 0 && t < Tn && hh2 >= 0 && hh2 < H && ww >= 0 && ww < W)
-                tot[(kt * 3 + kh) * 3 + kw] = fmaf(d, ET<T>::ld(xb + (1 + ((long)t * H + hh2) * W + ww) * C), tot[(kt * 3 + kh) * 3 + kw]);
-            }
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(d8[j], x8[j], acc[j]);
           }
         }
       }
     }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) red[grp][ch * 27 + k] = tot[k];
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 27 * HD; i += 256) {
-    float a = 0.f;
+  if (live) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) a += red[g][i];
-    part[(long)blockIdx.x * 27 * HD + i] = a;
+    for (int j = 0; j < 8; ++j) part[(long)blockIdx.x * 27 * HD + (chunk * 8 + j) * 27 + tap] = acc[j];
   }
 }
 
@@ -567,6 +615,7 @@ static int pool_check(const vtx_pool_desc* d, const char* who) {
   VTX_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->heads > 0 && d->sh > 0 && d->sw > 0, VTX_EINVAL, "%s: bad shape", who);
   return VTX_OK;
 }
+constexpr int POOL_W_BLOCKS = 2048;                                            // slices of the conv weight-gradient sum
 static inline int pooled(int n, int s) { return (n + 2 - 3) / s + 1; }        // kernel 3, padding 1
 
 extern "C" int vtx_pool_conv_ln_fwd(const vtx_pool_desc* d, const void* x, const float* w, const float* gamma, const float* beta,
@@ -576,7 +625,9 @@ extern "C" int vtx_pool_conv_ln_fwd(const vtx_pool_desc* d, const void* x, const
   VTX_REQUIRE(x && w && gamma && beta && pre && y && mean && rstd, VTX_EINVAL, "pool_conv_ln_fwd: null pointer");
   const int Ho = pooled(d->H, d->sh), Wo = pooled(d->W, d->sw);
   const long units = (long)d->B * (1 + (long)d->T * Ho * Wo) * d->heads;
-  dim3 g(cdiv(units, 8)), blk(256);
+  VTX_REQUIRE(units < (1L << 31) && (long)d->B * (1 + (long)d->T * d->H * d->W) < (1L << 31), VTX_EINVAL,
+              "pool_conv_ln_fwd: token grid too large for the 32-bit index arithmetic");
+  dim3 g(cdiv(units, d->hd == 96 ? 16 : 32)), blk(256);
   hipStream_t st = as_stream(stream);
 #define L_(T_, HD_) hipLaunchKernelGGL((pool_conv_ln_fwd_kernel<T_, HD_>), g, blk, 0, st, d->B, d->T, d->H, d->W, Ho, Wo, d->sh, d->sw, d->heads, \
                                        (const T_*)x, w, gamma, beta, eps, (T_*)pre, (T_*)y, mean, rstd)
@@ -587,7 +638,7 @@ extern "C" int vtx_pool_conv_ln_fwd(const vtx_pool_desc* d, const void* x, const
 
 extern "C" size_t vtx_pool_conv_ln_bwd_workspace(const vtx_pool_desc* d) {
   if (!d) return 0;
-  return ((size_t)1024 * 2 * d->hd + (size_t)512 * 27 * d->hd) * sizeof(float);
+  return ((size_t)1024 * 2 * d->hd + (size_t)POOL_W_BLOCKS * 27 * d->hd) * sizeof(float);
 }
 
 extern "C" int vtx_pool_conv_ln_bwd(const vtx_pool_desc* d, const void* dy, const void* x, const void* pre, const float* mean,
@@ -602,11 +653,13 @@ extern "C" int vtx_pool_conv_ln_bwd(const vtx_pool_desc* d, const void* dy, cons
   const long n_out = 1 + (long)d->T * Ho * Wo, units = (long)d->B * n_out * d->heads;
   hipStream_t st = as_stream(stream);
   float* part_ln = (float*)workspace;                        // [1024][2][hd]
-  float* part_w = part_ln + (size_t)1024 * 2 * d->hd;        // [512][27][hd]
+  float* part_w = part_ln + (size_t)1024 * 2 * d->hd;        // [POOL_W_BLOCKS][27][hd]
   const int nb_ln = (int)(cdiv(units, 8) > 1024 ? 1024 : cdiv(units, 8));
   const long pairs = (long)d->B * (n_out - 1);
-  const int nb_w = (int)(pairs < 512 ? (pairs > 0 ? pairs : 1) : 512);
-  const long in_elems = (long)d->B * (1 + (long)d->T * d->H * d->W) * C;
+  const long want_w = cdiv(pairs, 32);                       // >= 32 pairs per block
+  const int nb_w = (int)(want_w < 1 ? 1 : want_w > POOL_W_BLOCKS ? POOL_W_BLOCKS : want_w);
+  VTX_REQUIRE(d->T < 255 && d->H < 4095 && d->W < 4095 && (long)d->B * (1 + (long)d->T * d->H * d->W) < (1L << 31),
+              VTX_EINVAL, "pool_conv_ln_bwd: token grid too large for the 32-bit index arithmetic");
 #define LN_(T_, HD_) hipLaunchKernelGGL((pool_ln_bwd_kernel<T_, HD_>), dim3(nb_ln), dim3(256), 0, st, units, d->heads, (const T_*)dy, (const T_*)pre, \
                                         mean, rstd, gamma, (T_*)dpre, part_ln)
   MV_DISPATCH(d->dtype, d->hd, LN_(float, 96), LN_(bf16raw, 96), LN_(float, 64), LN_(bf16raw, 64), "pool_conv_ln_bwd");
@@ -615,14 +668,14 @@ extern "C" int vtx_pool_conv_ln_bwd(const vtx_pool_desc* d, const void* dy, cons
   if (rc) return rc;
   rc = launch_reduce_partials(part_ln, nb_ln, 2L * d->hd, 2L * d->hd, dgamma, 0, 1.0f, st, dbeta, d->hd, 0);
   if (rc) return rc;
-#define BD_(T_, HD_) hipLaunchKernelGGL((pool_conv_bwd_data_kernel<T_, HD_>), dim3(grid_for(in_elems)), dim3(256), 0, st, d->B, d->T, d->H, d->W, Ho, Wo, \
-                                        d->sh, d->sw, C, (const T_*)dpre, w, (T_*)dx)
+#define BD_(T_, HD_) hipLaunchKernelGGL((pool_conv_bwd_data_kernel<T_, HD_>), dim3(d->B * (d->T * d->H + 1)), dim3(256), 0, st, d->B, d->T, d->H, d->W, \
+                                        Ho, Wo, d->sh, d->sw, C, (const T_*)dpre, w, (T_*)dx)
   MV_DISPATCH(d->dtype, d->hd, BD_(float, 96), BD_(bf16raw, 96), BD_(float, 64), BD_(bf16raw, 64), "pool_conv_ln_bwd");
 #undef BD_
   rc = check_launch("pool_conv_bwd_data");
   if (rc) return rc;
-#define BW_(T_, HD_) hipLaunchKernelGGL((pool_conv_bwd_weight_kernel<T_, HD_>), dim3(nb_w), dim3(256), 0, st, d->B, d->T, d->H, d->W, Ho, Wo, d->sh, \
-                                        d->sw, d->heads, (const T_*)dpre, (const T_*)x, part_w)
+#define BW_(T_, HD_) hipLaunchKernelGGL((pool_conv_bwd_weight_kernel<T_, HD_>), dim3(nb_w), dim3((HD_ / 8) * 32), 0, st, d->B, d->T, d->H, d->W, Ho, Wo, \
+                                        d->sh, d->sw, d->heads, (const T_*)dpre, (const T_*)x, part_w)
   MV_DISPATCH(d->dtype, d->hd, BW_(float, 96), BW_(bf16raw, 96), BW_(float, 64), BW_(bf16raw, 64), "pool_conv_ln_bwd");
 #undef BW_
   rc = check_launch("pool_conv_bwd_weight");
