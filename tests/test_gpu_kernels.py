@@ -605,6 +605,55 @@ def test_attention_mfma_matches_valu(S, L, vtx_opts):
     check(f'attn mfma vs valu dqkv S={S} L={L}', res['0'][2], res['1'][2], 2e-2)
 
 
+@pytest.mark.parametrize('mode,S,L,H', [('contig', 3, 197, 3), ('contig', 5, 33, 2), ('contig', 2, 224, 2), ('contig', 4, 130, 12),
+                                        ('space', 0, 197, 3), ('space', 0, 37, 2), ('contig', 2, 256, 2)])
+def test_attention_backward_one_pass_equals_two_kernels(mode, S, L, H, vtx_opts):
+    """Backward of the 33..224-token attention: the one-pass kernel (dq, dk, dv from tiles that stay in LDS) and the dq + dk/dv
+    kernel pair (all four unrolled / rolled variants) do the same products and sums in the same order: bit-identical
+    gradients, ragged last tiles, both row addressings; 225..256 tokens only have the pair."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG, ATTN_SPACE
+    hd = 64
+    D = H * hd
+    bf = torch.bfloat16
+    if mode == 'contig':
+        qkv = dev(rnd(S, L, 3 * D, seed=L) * 1.5, bf)
+        do = dev(rnd(S, L, D, seed=L + 1), bf)
+        args = (ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        new_out = lambda: torch.empty(S, L, D, dtype=bf, device=DEV)                      # noqa: E731
+        nlse = S * H * L
+        new_dqkv = lambda: (torch.full((S, L, 3 * D), float('nan'), dtype=bf, device=DEV), None)   # noqa: E731
+    else:
+        B, T, P = 2, 3, L - 1
+        N = P * T
+        qkv = dev(rnd(B, 1 + N, 3 * D, seed=L) * 1.5, bf)
+        do = dev(rnd(B * N + B * T, D, seed=L + 1), bf)
+        args = (ATTN_SPACE, B * T, L, H, hd, hd ** -0.5, B, T, P)
+        new_out = lambda: torch.empty(B * N + B * T, D, dtype=bf, device=DEV)             # noqa: E731
+        nlse = B * T * H * L
+        new_dqkv = lambda: (torch.zeros(B, 1 + N, 3 * D, dtype=bf, device=DEV),           # noqa: E731
+                            torch.full((B * T, 3 * D), float('nan'), dtype=bf, device=DEV))
+    o = new_out()
+    lse = torch.empty(nlse, device=DEV)
+    ops.attn_fwd(qkv, o, lse, *args)
+    res = []
+    for fused, dkv in (('1', '3'), ('0', '3'), ('0', '0'), ('0', '1')):
+        vtx_opts('attn_fused', fused)
+        vtx_opts('attn_dkv', dkv)
+        dqkv, dcls = new_dqkv()
+        if dcls is None:
+            ops.attn_bwd(qkv, o, lse, do, dqkv, *args)
+        else:
+            ops.attn_bwd(qkv, o, lse, do, dqkv, *args, dqkv_cls=dcls)
+        torch.cuda.synchronize()
+        res.append((dqkv, dcls))
+    assert torch.isfinite(res[0][0].float()).all()
+    for dqkv, dcls in res[1:]:
+        assert torch.equal(dqkv, res[0][0])
+        if dcls is not None:
+            assert torch.equal(dcls, res[0][1])
+
+
 # ----------------------------------------------------------------------------- glue ops
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_glue_ops(dtype):

@@ -47,13 +47,14 @@ __device__ inline int sw_off(int row, int col) { return row * 64 + ((((col >> 3)
 // Fill TWO swizzled LDS tiles (rows gathered through rowfn0 / rowfn1, zero rows beyond nvalid, up to
 // Lp <= 256).  All global loads of both tiles are issued before the first LDS store: a load->store
 // loop serialises one memory latency per iteration (measured: ~25 us of a 50 us workgroup).
-template <typename RowFn0, typename RowFn1>
+template <int NTHR = 256, typename RowFn0, typename RowFn1>
 __device__ inline void fill_tiles2(bf16raw* lds0, bf16raw* lds1, int Lp, int nvalid, const bf16raw* base0, long ld0, int col0,
                                    RowFn0 rowfn0, const bf16raw* base1, long ld1, int col1, RowFn1 rowfn1) {
-  uint4 v0[8], v1[8];
+  constexpr int NI = 2048 / NTHR;
+  uint4 v0[NI], v1[NI];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int id = threadIdx.x + i * MA_THREADS;
+  for (int i = 0; i < NI; ++i) {
+    const int id = threadIdx.x + i * NTHR;
     const int r = id >> 3, c = id & 7;
     v0[i] = make_uint4(0, 0, 0, 0);
     v1[i] = make_uint4(0, 0, 0, 0);
@@ -63,8 +64,8 @@ __device__ inline void fill_tiles2(bf16raw* lds0, bf16raw* lds1, int Lp, int nva
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int id = threadIdx.x + i * MA_THREADS;
+  for (int i = 0; i < NI; ++i) {
+    const int id = threadIdx.x + i * NTHR;
     const int r = id >> 3, c = id & 7;
     if (id < Lp * 8) {
       const int off = r * 64 + ((c ^ sw_of(r)) << 3);
@@ -358,6 +359,16 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_fwd_mfma_kernel(AttnP p, c
   }
 }
 
+// The four row-wise fragments of a 32-row tile (one row per lane) written into a swizzled [32][64] LDS tile.
+__device__ inline void put_tile(bf16raw* lds, const bf16x8 (&f)[4], int lane) {
+  const int row = lane & 31;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = ks * 2 + (lane >> 5);
+    *reinterpret_cast<bf16x8*>(lds + row * 64 + ((c ^ sw_of(row)) << 3)) = f[ks];
+  }
+}
+
 // --------------------------------------------------------------------------- backward: dq
 template <int NT_>
 __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dq_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
@@ -541,6 +552,254 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
   }
 }
 
+// ------------------------------------------------------------------- backward: dq, dk, dv in one pass over HBM
+// The two kernels above each read q, k, v and dO (and o) of the (sequence, head).  For up to 7 tiles (L <= 224: the 197
+// of every model here) ONE workgroup of 8 waves keeps all four operands on chip: K, V, Q, dO tiles in LDS (4 x 28 KB) +
+// per-wave staging, one workgroup per CU, persistent over the (sequence, head) items (heads fastest: the CUs of a round
+// read whole 4.6-KB rows of qkv between them).  Wave w < nt owns query tile w in the dq phase and key tile w in the
+// dk / dv phase; wave 7 never owns a tile and is the LOADER.  Per item:
+//   top:    the worker's Q / dO / O row fragments (already in registers: loaded behind the previous item's last
+//           products) -> delta = rowsum(dO * O), Q and dO fragments copied into the LDS tiles, lse * log2(e) and delta
+//           into LDS;                                                          barrier A
+//   dq:     the dq kernel's tile body on the K / V tiles; then the wave takes its own K / V fragments out of the tiles
+//           (same values and lane layout as the dkv kernel's global loads);     barrier B (K / V tiles are free)
+//   dk/dv:  the dkv kernel's tile body on the Q / dO tiles, WHILE the loader brings the next item's K and V tiles from
+//           HBM into the free K / V space (LDS-DMA); behind its last product a worker requests
+//           the next item's row fragments, then stores dk, dv;                  barrier C (Q / dO tiles are free)
+// so the only exposed memory time per item is what the loader / the fragment loads do not finish under the dk/dv phase.
+// The dq phase is software-pipelined by hand: the score / dP products of tile pair i + 1 are issued BEFORE the exp / pack
+// work of pair i (same products, same sums, same order per accumulator; the same in the dk / dv phase costs 30 registers
+// the kernel does not have and measured 1.5 %).  Results are bit-identical to the two-kernel
+// path (tests/test_gpu_kernels.py::test_attention_backward_one_pass_equals_two_kernels).
+constexpr int MF_THREADS = 512;
+constexpr int MF_LOADER = 7;
+
+// the loader wave: rows [0, Lp) of the K and V tiles of (li, h) HBM -> LDS with global_load_lds_dwordx4 (no registers: all
+// 2 x Lp / 8 requests of 1 KB are in flight at once; a wave-instruction lands 8 tile rows in lane order, so the chunk swizzle
+// is applied to the SOURCE address).  Rows beyond nvalid must read as zero: their lanes fetch from a 16-byte block of zeros.
+__device__ __attribute__((aligned(16))) unsigned g_attn_zero16[4];
+__device__ inline void loader_fill_kv(bf16raw* Ks, bf16raw* Vs, int Lp, int nvalid, const bf16raw* qkv, long ld, int D, int h,
+                                      const RowLin& li, int lane) {
+  const bf16raw* zeros = reinterpret_cast<const bf16raw*>(g_attn_zero16);
+  const int rl = lane >> 3, pc = lane & 7;
+#pragma unroll 4
+  for (int g = 0; g < Lp / 8; ++g) {
+    const int r = g * 8 + rl;
+    const bf16raw* src = qkv + lin_row(li, r < nvalid ? r : 0) * ld + h * 64 + ((pc ^ sw_of(r)) << 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r < nvalid ? src + D : zeros),
+                                     (__attribute__((address_space(3))) void*)(Ks + g * 512), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r < nvalid ? src + 2 * D : zeros),
+                                     (__attribute__((address_space(3))) void*)(Vs + g * 512), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NT_>
+__global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_fused_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+                                                                         const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
+                                                                         const float* __restrict__ lse, bf16raw* __restrict__ dqkv,
+                                                                         bf16raw* __restrict__ dqkv_cls) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int D = p.H * 64, items = p.S * p.H;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nt = NT_ > 0 ? NT_ : (p.L + 31) >> 5, Lp = nt * 32;
+  bf16raw* Ks = reinterpret_cast<bf16raw*>(sm_raw);
+  bf16raw* Vs = Ks + Lp * 64;
+  bf16raw* Qs = Vs + Lp * 64;
+  bf16raw* Os = Qs + Lp * 64;                       // dO
+  bf16raw* stg = Os + Lp * 64 + wave * MA_STAGE_ELEMS;
+  float* Ls = reinterpret_cast<float*>(Os + Lp * 64 + 8 * MA_STAGE_ELEMS);   // lse * log2(e), +huge on padded rows
+  float* Ds = Ls + Lp;
+  const bool worker = wave < nt;
+  const int q = wave * 32 + (lane & 31);            // the wave's query row (dq phase) = its key row (dk / dv phase)
+  const float c2 = p.scale * LOG2E;
+  const int ragged = (p.L & 31) ? nt - 1 : -1;
+  FragOff fo = make_frag_off(lane);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifndef VTX_FUSED_ABLATE
+#define VTX_FUSED_ABLATE 0                          // timing experiments only: 1 = no dq phase, 2 = no dk / dv phase, 3 = neither
+#endif
+
+  // The three roles run their own copies of the item loop (same item sequence, same number of barriers): the register
+  // allocator sees the loader's addresses and the workers' accumulators in different code, not live together.
+  const int stride = gridDim.x;
+  if (blockIdx.x >= items) return;
+  if (wave == MF_LOADER) {
+    int item = blockIdx.x;
+    {
+      const int s = item / p.H;
+      loader_fill_kv(Ks, Vs, Lp, p.L, qkv, p.ld_qkv, D, item - s * p.H, lin_in(p, s), lane);
+    }
+    while (true) {
+      __syncthreads();                              // A
+      __syncthreads();                              // B: nobody reads the K / V tiles any more
+      const int next = item + stride;
+      if (next >= items) break;
+      const int sn = next / p.H;
+      loader_fill_kv(Ks, Vs, Lp, p.L, qkv, p.ld_qkv, D, next - sn * p.H, lin_in(p, sn), lane);
+      __syncthreads();                              // C
+      item = next;
+    }
+    return;
+  }
+  if (!worker) {                                    // fewer than 7 tiles: waves without a tile only keep the barrier count
+    for (int item = blockIdx.x;; item += stride) {
+      __syncthreads();
+      __syncthreads();
+      if (item + stride >= items) break;
+      __syncthreads();
+    }
+    return;
+  }
+
+  int item = blockIdx.x;
+  int s = item / p.H, h = item - s * p.H;
+  RowLin li = lin_in(p, s), lo = lin_out(p, s);
+  bf16x8 qf[4], df[4], of[4];
+  load_row_frags(qf, qkv, p.ld_qkv, h * 64, li, q, p.L, lane);
+  load_row_frags(df, dout, p.ld_dout, h * 64, lo, q, p.L, lane);
+  load_row_frags(of, o, p.ld_out, h * 64, lo, q, p.L, lane);
+  float l2 = q < p.L ? lse[((long)s * p.H + h) * p.L + q] * LOG2E : 0.f;
+
+  auto scores_dq = [&](int kt, f32x16& st, f32x16& dp) {
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, kt * 32, 0, fo), qf[0], zero, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Vs, kt * 32, 0, fo), df[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, kt * 32, ks, fo), qf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Vs, kt * 32, ks, fo), df[ks], dp, 0, 0, 0);
+    }
+  };
+
+  while (true) {
+    // the lane's fragment offsets are made opaque once per item: every LDS address of the unrolled phases is (offset +
+    // constant), loop-invariant, and hoisted out of the item loop they would need a few hundred registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.rows[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.cols[i >> 1][i & 1]));
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dl = frag_dot2(df[ks], of[ks], dl);
+    dl += __shfl_xor(dl, 32, 64);
+    put_tile(Qs + wave * 32 * 64, qf, lane);
+    put_tile(Os + wave * 32 * 64, df, lane);
+    if (lane < 32) {
+      Ls[q] = q < p.L ? l2 : 1e30f;
+      Ds[q] = q < p.L ? dl : 0.f;
+    }
+    __syncthreads();                                // A: this item's four tiles, lse and delta are in LDS
+    if (!(VTX_FUSED_ABLATE & 1)) {                  // ---- dq of query tile `wave` (attn_bwd_dq_mfma_kernel's tile body)
+      f32x16 acc[2];
+      zero16(acc[0]);
+      zero16(acc[1]);
+      f32x16 st, dp;
+      scores_dq(0, st, dp);
+#pragma unroll(NT_ > 0 ? NT_ : 1)
+      for (int kt = 0; kt < nt; ++kt) {
+        f32x16 stn = zero, dpn = zero;
+        if (kt + 1 < nt) scores_dq(kt + 1, stn, dpn);
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -l2)) * (dp[r] - dl);
+        if (kt == ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + crow(r, lane) >= p.L) ds[r] = 0.f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 db = pack8(ds + 8 * s2);
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+            acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Ks, kt * 32 + 16 * s2, n2, fo), db, acc[n2], 0, 0, 0);
+        }
+        st = stn;
+        dp = dpn;
+      }
+      store_rows_T(stg, acc, p.scale, lane, [&](int r) -> bf16raw* {
+        const int qq = wave * 32 + r;
+        if (qq >= p.L) return nullptr;
+        return (p.mode == VTX_ATTN_SPACE && qq == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
+                                                      : dqkv + lin_row(li, qq) * p.ld_dqkv + h * 64;
+      });
+    }
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_rows_o(Ks, wave * 32, ks, fo);
+      vf[ks] = frag_rows_o(Vs, wave * 32, ks, fo);
+    }
+    __syncthreads();                                // B: nobody reads the K / V tiles any more (the loader refills them)
+    const int next = item + stride;
+    const bool more = next < items;
+    const int nx = more ? next : item;              // last item: the prefetch below re-reads the current rows (unused)
+    const int sn = nx / p.H, hn = nx - sn * p.H;
+    const RowLin lin = lin_in(p, sn), lon = lin_out(p, sn);
+    f32x16 dk[2], dv[2];
+    zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+    if (!(VTX_FUSED_ABLATE & 2)) {                  // ---- dk, dv of key tile `wave` (attn_bwd_dkv_mfma_kernel's tile body)
+      auto scores_dkv = [&](int qt, f32x16& st, f32x16& dp) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, 0, fo), kf[0], zero, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, 0, fo), vf[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, ks, fo), kf[ks], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, ks, fo), vf[ks], dp, 0, 0, 0);
+        }
+      };
+#pragma unroll(NT_ > 0 ? NT_ : 1)
+      for (int qt = 0; qt < nt; ++qt) {
+        f32x16 st, dp;
+        scores_dkv(qt, st, dp);
+        // padded query rows: Ls = +huge -> P = 0; padded keys only feed dk/dv rows that are never stored
+        float pr[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int qrow = qt * 32 + 8 * g + 4 * (lane >> 5);
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls + qrow);
+          const float4 d4 = *reinterpret_cast<const float4*>(Ds + qrow);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lv[j]));
+            pr[r] = e;
+            ds[r] = e * (dp[r] - dvv[j]);            // the softmax scale is applied once to dk at the store
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack8(pr + 8 * s2);
+          const bf16x8 db = pack8(ds + 8 * s2);
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) {
+            dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, qt * 32 + 16 * s2, n2, fo), pb, dv[n2], 0, 0, 0);
+            dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, qt * 32 + 16 * s2, n2, fo), db, dk[n2], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // the next item's row fragments, in flight under the dk / dv stores
+    load_row_frags(qf, qkv, p.ld_qkv, hn * 64, lin, q, p.L, lane);
+    load_row_frags(df, dout, p.ld_dout, hn * 64, lon, q, p.L, lane);
+    load_row_frags(of, o, p.ld_out, hn * 64, lon, q, p.L, lane);
+    l2 = q < p.L ? lse[((long)sn * p.H + hn) * p.L + q] * LOG2E : 0.f;
+    if (!(VTX_FUSED_ABLATE & 2)) {
+      auto base_of = [&](int r) -> bf16raw* {
+        const int kk = wave * 32 + r;
+        if (kk >= p.L) return nullptr;
+        return (p.mode == VTX_ATTN_SPACE && kk == 0) ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + lin_row(li, kk) * p.ld_dqkv;
+      };
+      store_rows_T(stg, dk, p.scale, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + D + h * 64 : nullptr; });
+      store_rows_T(stg, dv, 1.0f, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + 2 * D + h * 64 : nullptr; });
+    }
+    if (!more) break;
+    __syncthreads();                                // C: nobody reads the Q / dO tiles, lse or delta any more
+    item = next; s = sn; h = hn; li = lin; lo = lon;
+  }
+}
+
 // =====================================================================================
 // Short sequences (L <= 32, contiguous rows): temporal attention of the divided block
 // (L = T = 8) and ViViT's temporal encoder (L = 9).  G = 32/L sequences are packed into one
@@ -552,14 +811,6 @@ __global__ __launch_bounds__(MA_THREADS, 2) void attn_bwd_dkv_mfma_kernel(AttnP 
 constexpr int SM_WAVE_LDS_FWD = 32 * 64 * 2;                   // V tile
 constexpr int SM_WAVE_LDS_BWD = 2 * 32 * 64 * 2 + 2 * 32 * 4;   // tile A (K, then Q), tile B (dO) + lse + delta
 
-__device__ inline void put_tile(bf16raw* lds, const bf16x8 (&f)[4], int lane) {
-  const int row = lane & 31;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int c = ks * 2 + (lane >> 5);
-    *reinterpret_cast<bf16x8*>(lds + row * 64 + ((c ^ sw_of(row)) << 3)) = f[ks];
-  }
-}
 __device__ inline void load_frags(bf16x8 (&f)[4], const bf16raw* base, long ld, int col0, long row, bool valid, int lane) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -842,9 +1093,26 @@ static int attn_bwd_mfma_launch_t(const AttnP& p, const void* qkv, const void* o
   return check_launch("attn_bwd_dkv_mfma");
 }
 
+template <int NT_>
+static int attn_bwd_fused_launch_t(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                                   void* dqkv_cls, hipStream_t st) {
+  const int Lp = ((p.L + 31) >> 5) * 32;
+  const size_t lds = (size_t)4 * Lp * 64 * 2 + 8 * MA_STAGE_ELEMS * 2 + (size_t)2 * Lp * 4;
+  allow_lds<attn_bwd_fused_mfma_kernel<NT_>>(lds);
+  const int items = p.S * p.H, cus = device_cus();          // one workgroup per CU (its LDS holds one item), persistent
+  hipLaunchKernelGGL(attn_bwd_fused_mfma_kernel<NT_>, dim3(items < cus ? items : cus), dim3(MF_THREADS), lds, st, p, (const bf16raw*)qkv,
+                     (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv, (bf16raw*)dqkv_cls);
+  return check_launch("attn_bwd_fused_mfma");
+}
+
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
-  if (((p.L + 31) >> 5) == 7) {
+  const int nt = (p.L + 31) >> 5;
+  if (options().attn_fused && nt <= 7) {           // one pass over HBM: all four operand tiles fit the LDS of one workgroup
+    if (nt == 7) return attn_bwd_fused_launch_t<7>(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
+    return attn_bwd_fused_launch_t<0>(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
+  }
+  if (nt == 7) {
     switch (options().attn_dkv) {                  // dk / dv kernel: 0 = run-time tile loop, 1..4 = unrolled variants
       case 1: return attn_bwd_mfma_launch_t<7, 7, 1>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);
       case 2: return attn_bwd_mfma_launch_t<7, 7, 0>(p, qkv, o, dout, lse, delta, dqkv, dqkv_cls, st);

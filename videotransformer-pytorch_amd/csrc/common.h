@@ -172,6 +172,7 @@ struct Options {
   int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
   int attn_hw_fwd = 16;      // VTX_ATTN_HW_FWD / _BWD: short-sequence attention with n heads of a row tile in one workgroup
   int attn_hw_bwd = 0;       //   (0: one head per workgroup, four row tiles)
+  int attn_fused = 1;        // VTX_ATTN_FUSED: backward of the 33..224-token attention as one kernel (dq, dk, dv from one pass over HBM); 0 = dq + dkv kernels
   int attn_dkv = 3;          // VTX_ATTN_DKV: dk / dv kernel of the 197-token attention: 0 = run-time query-tile loop, 1..4 = unrolled variants
                              // (3 = unrolled, next key tile loaded behind the current one: profiles/round3_attn_dkv_variants.txt)
   int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
@@ -208,6 +209,19 @@ inline bool first_launch_on_device(std::atomic<unsigned long long>& seen) {
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   return (seen.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+}
+
+// compute units of the current device (asked once per device)
+inline int device_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v <= 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
