@@ -149,6 +149,40 @@ def pmc_traffic_per_launch(B, args):
     return round(tot, 0) if tot > 0 else None
 
 
+def pmc_mfma_busy(B, args):
+    """Matrix-pipe occupancy per GEMM class REPLAYED from the committed `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
+    GRBM_GUI_ACTIVE` pass of THIS command (profiles/round<N>_pmc_MFMA_BUSY_b<B>.txt, kernel names pooled over template
+    instantiations).  SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of every SIMD's matrix pipe (32 per v_mfma_f32_32x32x16_bf16:
+    MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is reported summed over the 8 XCDs.  busy = MFMA_BUSY / (GRBM / 8 * 1024 SIMDs): the
+    fraction of SIMD-cycles AT THE CLOCK THE KERNEL RAN AT with the matrix pipe busy -- roofline.frac prices the same work
+    against the nominal 2.4 GHz peak, the ratio of the two is the clock the power budget allowed."""
+    if args.precision != 'bf16' or args.frames != 8:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        path = next(pth for pth in (os.path.join(here, 'profiles', r + f'pmc_MFMA_BUSY_b{B}.txt') for r in PMC_ROUNDS) if os.path.isfile(pth))
+    except StopIteration:
+        return None
+    acc = {}
+    for line in open(path):
+        cls = 'gemm_nt' if 'nt_bf16_pp_kernel' in line else 'gemm_tn' if 'tn_bf16_pp_kernel' in line else None
+        if cls is None:
+            continue
+        try:
+            f = dict(kv.split('=') for kv in line.split() if '=' in kv)
+            counter = next(c for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE') if c in line)
+            acc.setdefault(cls, {}).setdefault(counter, 0.0)
+            acc[cls][counter] += float(f['total'])
+        except (StopIteration, KeyError, ValueError):
+            continue
+    out = {c: round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4)
+           for c, v in acc.items() if v.get('GRBM_GUI_ACTIVE') and 'SQ_VALU_MFMA_BUSY_CYCLES' in v}
+    if not out:
+        return None
+    out['source'] = 'replayed: ' + os.path.relpath(path, here)
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -335,6 +369,7 @@ def main():
                          'traffic': pmc_traffic_per_launch(B, args),
                          'traffic_source': 'replayed: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command under profiles/ '
                                            '(2 x FETCH_SIZE + WRITE_SIZE per launch), not counted in this run',
+                         'mfma_busy': pmc_mfma_busy(B, args),
                          'launches': n, 'avg_launch_us': round(ms / max(n, 1) * 1e3, 2),
                          'flops_per_launch_avg': round(flops / max(n, 1), 0),
                          'algorithmic_bytes_per_launch_avg': round(nbytes / max(n, 1), 0)},

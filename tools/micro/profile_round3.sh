@@ -30,3 +30,7 @@ cat $O/${TAG}_batch_sweep.txt
 # 5. other BASELINE configurations
 timeout 900 python tools/other_configs.py hog vivit tsf16 tsfl96_stored tsfl96_12 > $O/${TAG}_other_configs.txt 2>&1; cut -c1-250 $O/${TAG}_other_configs.txt
 timeout 300 python tools/maskfeat_bench.py 32 3 > $O/${TAG}_maskfeat.txt 2>&1; tail -1 $O/${TAG}_maskfeat.txt
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_mf -- python $R/tools/maskfeat_bench.py 32 3 > /tmp/mf.log 2>&1
+python $R/tools/rocpd_stats.py /tmp/prof_mf > $O/${TAG}_maskfeat_kernel_stats.csv
+cd $R
