@@ -214,12 +214,34 @@ def respawn_under_torchrun(args):
 
 
 def gemm_shape_table(per_shape, peak_tf):
-    """[{shape, launches_per_step, avg_us, tflops, alg_mb, tb_per_s, bound, frac}] from ops.profile_stop() entries."""
+    """[{shape, launches_per_step, avg_us, tflops, alg_mb, tb_per_s, bound, frac}] from ops.profile_stop() entries.  Launches that
+    differ only in M by less than 15 % are pooled into one row `Mmin..MmaxxNxK` (the FFN runs on the clips DropPath keeps: a
+    different M per layer and step; temporal / spatial row counts 150528 / 150624 / 151296)."""
+    groups = {}
+    for key, (n, ms, fl, by) in per_shape.items():
+        dims, _, epi = key.partition('+')
+        try:
+            M, N, K = (int(v) for v in dims.split('x'))
+        except ValueError:
+            groups[(key, None, None, 0)] = [key, key, n, ms, fl, by]
+            continue
+        for g in groups:
+            if g[1:3] == (N, K) and g[0] == epi and isinstance(g[3], int) and g[3] and abs(M - g[3]) <= 0.15 * g[3]:
+                v = groups[g]
+                v[0], v[1] = min(v[0], M), max(v[1], M)
+                v[2] += n; v[3] += ms; v[4] += fl; v[5] += by
+                break
+        else:
+            groups[(epi, N, K, M)] = [M, M, n, ms, fl, by]
     rows = []
-    for key, (n, ms, fl, by) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
+    for (epi, N, K, _), (m0, m1, n, ms, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][3]):
+        if N is None:
+            shape = m0
+        else:
+            shape = (f'{m0}x{N}x{K}' if m0 == m1 else f'{m0}..{m1}x{N}x{K}') + (f'+{epi}' if epi else '')
         t = ms * 1e-3 / n
         t_m, t_h = fl / n / (peak_tf * 1e12), by / n / (PEAK_HBM * 1e12)
-        rows.append({'shape': key, 'launches': n, 'avg_us': round(t * 1e6, 1), 'tflops': round(fl / n / t / 1e12, 1),
+        rows.append({'shape': shape, 'launches': n, 'avg_us': round(t * 1e6, 1), 'tflops': round(fl / n / t / 1e12, 1),
                      'alg_mb': round(by / n / 1e6, 1), 'tb_per_s': round(by / n / t / 1e12, 2),
                      'bound': 'mfma' if t_m >= t_h else 'hbm', 'frac': round(max(t_m, t_h) / t, 3)})
     return rows
