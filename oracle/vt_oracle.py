@@ -192,6 +192,23 @@ def patch_embed(x, sd, pre='patch_embed.projection.'):
 # --------------------------------------------------------------------------
 # models
 # --------------------------------------------------------------------------
+def interpolated_pos_embed(pos_embed, npatch, w, h, patch):
+    """TimeSformer.interpolate_pos_encoding (video_transformer.py:171-191): the table as it is when the clip has the patch grid
+    the model was built for and is square, else a bicubic resize of the patch part.  Kept quirks: both grid sides are divided by
+    patch_size[0]; the WIDTH ratio scales the first grid axis although the tokens are (h w)-ordered; 0.1 is added to each side
+    before the ratio (the DINO float-rounding workaround)."""
+    n = pos_embed.shape[1] - 1
+    if npatch == n and w == h:
+        return pos_embed
+    d = pos_embed.shape[-1]
+    side = int(math.sqrt(n))
+    w0, h0 = w // patch + 0.1, h // patch + 0.1
+    grid = pos_embed[:, 1:].reshape(1, side, side, d).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, scale_factor=(w0 / math.sqrt(n), h0 / math.sqrt(n)), mode='bicubic')
+    assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+    return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, d)], dim=1)
+
+
 def _tokens_with_time(tok, sd, b):
     """Shared tail of prepare_tokens for every non-factorised attention type
     (video_transformer.py:199-238 / :461-500, use_cls_token_temporal=False):
@@ -213,6 +230,10 @@ def timesformer_forward(sd, x, num_frames, heads=12, layers=12,
     (video_transformer.py:193-261)."""
     b = x.shape[0]
     tok = patch_embed(x, sd)
+    patch = sd['patch_embed.projection.weight'].shape[-1]
+    pe = interpolated_pos_embed(sd['pos_embed'], tok.shape[1], x.shape[-1], x.shape[-2], patch)      # (:209)
+    if pe is not sd['pos_embed']:
+        sd = dict(sd, pos_embed=pe)
     if attention_type == 'space_only':
         bt, P, d = tok.shape
         h = torch.cat([sd['cls_token'].expand(bt, 1, d), tok], dim=1) + sd['pos_embed']

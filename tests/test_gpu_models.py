@@ -70,6 +70,32 @@ def test_timesformer_small_vs_golden(at, prec, tol, gtol):
 
 
 @pytest.mark.parametrize('prec,tol,gtol', PRECS)
+@pytest.mark.parametrize('hw', [(96, 96), (64, 96), (32, 32)])
+def test_timesformer_other_resolution_vs_oracle(hw, prec, tol, gtol):
+    """A clip of another resolution than img_size: the positional table is resized (reference video_transformer.py:171-191,
+    :209, non-square quirk included) and its gradient flows back through the resize to pos_embed.  Oracle = the
+    reference-pinned restatement (tests/test_oracle_pin.py::test_timesformer_other_resolution)."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    m, sd = _build(V.TimeSformer, 6, num_frames=2, **SMALL)
+    x = synth.synth_clip(2, 2, 3, hw[0], hw[1], seed=3)
+    m.eval()
+    m.zero_grad()
+    y = m(x.to(DEV))
+    w = (synth_tensor('loss_w', (128,), 0) * 10.0)
+    (y * w.to(DEV)).sum().backward()
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = O.timesformer_forward(ps, x, 2, heads=2, layers=2)
+    (yo * w).sum().backward()
+    check(f'tsf other resolution {hw} {prec} out', y.detach().cpu(), yo.detach(), tol)
+    for k in ('pos_embed', 'time_embed', 'cls_token', 'patch_embed.projection.weight'):
+        got, ref = dict(m.named_parameters())[k].grad.cpu(), ps[k].grad
+        e = (got.double() - ref.double()).norm().item() / ref.double().norm().item()
+        assert e <= gtol, (k, hw, prec, e)
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
 @pytest.mark.parametrize('at', ['fact_encoder', 'joint_space_time', 'divided_space_time'])
 def test_vivit_small_vs_golden(at, prec, tol, gtol):
     import vtx

@@ -44,6 +44,25 @@ def test_vivit(at):
     assert relerr(yo, y) < 1e-5
 
 
+@pytest.mark.parametrize('hw', [(96, 96), (64, 96), (96, 64), (32, 32)])
+@pytest.mark.parametrize('at', ['divided_space_time', 'space_only'])
+def test_timesformer_other_resolution(at, hw):
+    """Clips of another resolution than img_size go through interpolate_pos_encoding (reference video_transformer.py:171-191,
+    :209): bicubic resize of the positional table, with the reference's width / height quirk for non-square clips."""
+    R = ref_loader.load()
+    m = R.video_transformer.TimeSformer(num_frames=2, attention_type=at, **SM)
+    sd = synth.synth_state_dict(synth.shapes_of(m), 6)
+    m.load_state_dict(sd)
+    m.eval()
+    x = synth.synth_clip(2, 2, 3, hw[0], hw[1])
+    y = m(x)
+    yo = O.timesformer_forward(sd, x, 2, heads=2, layers=3, attention_type=at)
+    assert relerr(yo, y) < 1e-5
+    pe = m.interpolate_pos_encoding(torch.empty(1, 1 + (hw[0] // 16) * (hw[1] // 16), 128), hw[1], hw[0])
+    po = O.interpolated_pos_embed(sd['pos_embed'], (hw[0] // 16) * (hw[1] // 16), hw[1], hw[0], 16)
+    assert torch.equal(pe.detach(), po)
+
+
 def test_droppath_rng_stream():
     """one training forward of TimeSformer-B (B=2,T=2) makes 33 torch.rand calls
     (layer 0 draws nothing); the oracle must consume the generator identically."""

@@ -50,10 +50,11 @@ class _VideoTransformerBase(nn.Module):
     def no_weight_decay_keywords(self):
         return {'pos_embed', 'cls_token', 'mask_token'}
 
-    def _tokens(self, x, layout, time_embed):
+    def _tokens(self, x, layout, time_embed, pos_embed=None):
         proj = self.patch_embed.projection
         dev = x.device
-        return F_.TokensFn.apply(x, proj.weight, proj.bias, self.cls_token, _embed(self.pos_embed, dev),
+        pos = _embed(self.pos_embed, dev) if pos_embed is None or pos_embed is self.pos_embed else pos_embed
+        return F_.TokensFn.apply(x, proj.weight, proj.bias, self.cls_token, pos,
                                  None if time_embed is None else _embed(time_embed, dev),
                                  vtx.compute_dtype(), layout)
 
@@ -124,25 +125,38 @@ class TimeSformer(_VideoTransformerBase):
                 raise TypeError(f'not support the pretrained weight {self.pretrain_pth}')
 
     def interpolate_pos_encoding(self, x, w, h):
-        """Identity when the patch grid matches pos_embed (always at the trained
-        resolution); bicubic resize otherwise (reference video_transformer.py:171-191)."""
+        """The positional table for a clip of width w and height h whose token tensor is x ([., 1 + patches, D]; only its
+        shape is read): pos_embed itself at the trained square resolution, otherwise its patch part resized bicubically to
+        the clip's patch grid (reference video_transformer.py:171-191, with its quirks: both sides divided by
+        patch_size[0], the width ratio applied to the first grid axis, +0.1 on each side before the ratio).  The resize is a
+        torch op on the [1, D, s, s] parameter view -- outside the per-layer path, differentiable, and never run at the
+        trained resolution."""
         npatch = x.shape[1] - 1
         n = self.pos_embed.shape[1] - 1
         if npatch == n and w == h:
             return self.pos_embed
-        raise NotImplementedError('vtx: positional-embedding interpolation (input resolution != img_size) '
-                                  'is not implemented on the HIP path')
+        side = int(math.sqrt(n))
+        ps = self.patch_embed.patch_size[0]
+        w0, h0 = w // ps + 0.1, h // ps + 0.1
+        table = self.pos_embed if isinstance(self.pos_embed, nn.Parameter) else self.pos_embed.detach()
+        grid = table[:, 1:].reshape(1, side, side, -1).permute(0, 3, 1, 2)
+        grid = nn.functional.interpolate(grid, scale_factor=(w0 / math.sqrt(n), h0 / math.sqrt(n)), mode='bicubic')
+        if (int(w0), int(h0)) != tuple(grid.shape[-2:]):
+            raise ValueError(f'pos_embed resize produced a {tuple(grid.shape[-2:])} grid for a {int(w0)} x {int(h0)} clip')
+        return torch.cat([table[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, table.shape[-1])], dim=1)
 
     def prepare_tokens(self, x):
         # x: float [B,T,C,H,W] (the reference's input) or, beyond the reference, the decoded uint8 clip
         # [B,T,H,W,3] with vtx.set_input_normalization(mean, std) (ToTensor + Normalize fused into the gather)
         b, t, c, h, w = vtx.ops.clip_dims(x)
-        grid = (h // self.patch_embed.patch_size[0]) * (w // self.patch_embed.patch_size[1])
-        if grid != self.pos_embed.shape[1] - 1 or w != h:
-            raise NotImplementedError('vtx: input resolution must match img_size (no pos-embed interpolation)')
+        ps = self.patch_embed.patch_size
+        grid = (h // ps[0]) * (w // ps[1])
+        pos = self.interpolate_pos_encoding(torch.empty(0, 1 + grid, 0), w, h)
+        if pos is not self.pos_embed:
+            pos = pos.to(device=x.device, dtype=torch.float32)
         if self.attention_type == 'space_only':
-            return self._tokens(x, 'tp', None), b
-        return self._tokens(x, 'pt', self.time_embed), b
+            return self._tokens(x, 'tp', None, pos), b
+        return self._tokens(x, 'pt', self.time_embed, pos), b
 
     def forward(self, x):
         x, b = self.prepare_tokens(x)
