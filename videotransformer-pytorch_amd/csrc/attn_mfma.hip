@@ -20,10 +20,12 @@
 // rev3((row>>1)&7): conflict-free both for the row-wise ds_read_b128 operand reads and
 // for the 4-row x 16-column blocks of the transpose reads.
 //
-// Backward = two kernels, mirroring the two contractions:
-//   dq : lanes = queries (S^T layout);  dQ^T += K^T dS^T          (+ writes delta)
+// Backward = two phases, mirroring the two contractions:
+//   dq : lanes = queries (S^T layout);  dQ^T += K^T dS^T          (+ delta)
 //   dkv: lanes = keys    (S layout);    dV^T += dO^T P, dK^T += Q^T dS
-// FLOPs per (sequence, head): fwd 4*Lp^2*64, bwd 14*Lp^2*64 (incl. recompute).
+// run by ONE persistent kernel for up to 224 tokens (all four operand tiles stay in LDS: one pass over HBM,
+// attn_bwd_fused_mfma_kernel) and by two kernels (each with two tiles in LDS) for 225..256 tokens or option attn_fused=0;
+// the two forms are bit-identical.  FLOPs per (sequence, head): fwd 4*Lp^2*64, bwd 14*Lp^2*64 (incl. recompute).
 #include "attn_common.h"
 
 namespace vtx {

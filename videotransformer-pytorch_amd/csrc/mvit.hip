@@ -13,7 +13,9 @@
 //   pos_encoding   separable spatial + temporal position embedding and the cls token.
 //   im2col3d       rows of the overlapping Conv3d(3 -> 96, kernel (3,7,7), stride (2,4,4), padding (1,3,3)) stem.
 //
-// First-correct kernels: HBM/VALU bound, not tuned (the backbone is 70 GFLOP per clip against TimeSformer-B's 392).
+// The pooling kernels work on 8 channels per thread (16-byte accesses, 32-bit index arithmetic, conv weights in LDS as
+// [tap][channel]); maxpool / pos_encoding / im2col3d are one-element-per-thread kernels (the backbone is 70 GFLOP per clip
+// against TimeSformer-B's 392; DESIGN.md 4.6 has the step breakdown).
 #include "common.h"
 
 namespace vtx {
