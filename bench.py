@@ -264,13 +264,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     force_dp = os.environ.get('VTX_FORCE_DP', '0') == '1'     # 1-rank RCCL group: exercises the DP path on one GPU
-    if world > 1 or force_dp:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
     import __graft_entry__ as ge
     ge.ensure_built()
     import vtx
+    if world > 1 or force_dp:
+        from vtx import dp as _dp
+        _dp.init_process_group(dev, rank, world)   # launcher's MASTER_*; a one-rank group picks (and retries) its own port
     from vtx import dp, ops, optim, functions as F_
     import transformer as T
     import video_transformer as V

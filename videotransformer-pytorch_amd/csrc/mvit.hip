@@ -271,55 +271,69 @@ __global__ __launch_bounds__((HD / 8) * 32) void pool_conv_bwd_weight_kernel(int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// MaxPool3d (1,3,3)/(1,2,2)/(0,1,1) on the residual path; arg = winning tap (kh*3+kw), 255 for the cls row
+// MaxPool3d (1,3,3)/(1,2,2)/(0,1,1) on the residual path; arg = winning tap (kh*3+kw), 255 for the cls row.
+// A thread owns 8 consecutive channels of one token (16-byte accesses, 8 argument bytes at a time, 32-bit index arithmetic).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int C, const T* __restrict__ x,
                                                           T* __restrict__ y, uint8_t* __restrict__ arg) {
-  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
-  const long total = (long)B * n_out * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long bo = i / C;
-    const long o = bo % n_out;
-    const int b = (int)(bo / n_out);
-    const T* xb = x + (long)b * n_in * C + c;
-    if (o == 0) { y[i] = xb[0]; arg[i] = 255; continue; }
-    const long r = o - 1;
-    const int t = (int)(r / ((long)Ho * Wo)), ho = (int)((r / Wo) % Ho), wo = (int)(r % Wo);
-    float best = -INFINITY;
-    int bi = 0;
+  const unsigned C8 = (unsigned)C / 8, HoWo = (unsigned)Ho * Wo;
+  const unsigned n_in = 1 + (unsigned)Tn * H * W, n_out = 1 + (unsigned)Tn * HoWo;
+  const unsigned total = (unsigned)B * n_out * C8;                      // < 2^31 (checked by the launcher)
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const unsigned bo = i / C8, c0 = (i - bo * C8) * 8;
+    const unsigned b = bo / n_out, o = bo - b * n_out;
+    const T* xb = x + (long)b * n_in * C + c0;
+    const long oi = ((long)b * n_out + o) * C + c0;
+    float best[8];
+    unsigned bi[8];
+    if (o == 0) {
+      load8(xb, best);
+      store8(y + oi, best);
+      *reinterpret_cast<uint2*>(arg + oi) = make_uint2(0xffffffffu, 0xffffffffu);
+      continue;
+    }
+    const unsigned r = o - 1;
+    const unsigned t = r / HoWo, rr = r - t * HoWo, ho = rr / (unsigned)Wo, wo = rr - ho * Wo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
     for (int kh = 0; kh < 3; ++kh) {
-      const int hh = ho * 2 + kh - 1;
+      const int hh = (int)ho * 2 + kh - 1;
       if (hh < 0 || hh >= H) continue;
       for (int kw = 0; kw < 3; ++kw) {
-        const int ww = wo * 2 + kw - 1;
+        const int ww = (int)wo * 2 + kw - 1;
         if (ww < 0 || ww >= W) continue;
-        const float v = ET<T>::ld(xb + (1 + ((long)t * H + hh) * W + ww) * C);
-        if (v > best || v != v) { best = v; bi = kh * 3 + kw; }      // strictly greater (or NaN): the first maximum wins, as ATen
+        float v[8];
+        load8(xb + (1 + ((long)t * H + hh) * W + ww) * C, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = kh * 3 + kw; }   // strictly greater (or NaN): the first maximum wins, as ATen
       }
     }
-    ET<T>::st(y + i, best);
-    arg[i] = (uint8_t)bi;
+    store8(y + oi, best);
+    *reinterpret_cast<uint2*>(arg + oi) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                     bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(int B, int Tn, int H, int W, int Ho, int Wo, int C, const T* __restrict__ dy,
                                                           const uint8_t* __restrict__ arg, T* __restrict__ dx) {
-  const long n_in = 1 + (long)Tn * H * W, n_out = 1 + (long)Tn * Ho * Wo;
-  const long total = (long)B * n_in * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long bn = i / C;
-    const long n = bn % n_in;
-    const int b = (int)(bn / n_in);
-    const long ob = (long)b * n_out * C + c;
-    float a = 0.f;
+  const unsigned C8 = (unsigned)C / 8, HW = (unsigned)H * W;
+  const unsigned n_in = 1 + (unsigned)Tn * HW, n_out = 1 + (unsigned)Tn * Ho * Wo;
+  const unsigned total = (unsigned)B * n_in * C8;                       // < 2^31 (checked by the launcher)
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const unsigned bn = i / C8, c0 = (i - bn * C8) * 8;
+    const unsigned b = bn / n_in, n = bn - b * n_in;
+    const long ob = (long)b * n_out * C + c0;
+    float a[8];
     if (n == 0) {
-      a = ET<T>::ld(dy + ob);
+      load8(dy + ob, a);
     } else {
-      const long r = n - 1;
-      const int t = (int)(r / ((long)H * W)), h = (int)((r / W) % H), w = (int)(r % W);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      const unsigned r = n - 1;
+      const unsigned t = r / HW, rr = r - t * HW, hu = rr / (unsigned)W;
+      const int h = (int)hu, w = (int)(rr - hu * W);
       for (int kh = 0; kh < 3; ++kh) {
         const int hn = h - kh + 1;
         if (hn < 0 || (hn & 1) || hn / 2 >= Ho) continue;
@@ -327,11 +341,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(int B, int Tn, int H, 
           const int wn = w - kw + 1;
           if (wn < 0 || (wn & 1) || wn / 2 >= Wo) continue;
           const long o = ob + (1 + ((long)t * Ho + hn / 2) * Wo + wn / 2) * C;
-          if (arg[o] == kh * 3 + kw) a += ET<T>::ld(dy + o);
+          const uint2 ar = *reinterpret_cast<const uint2*>(arg + o);
+          float v[8];
+          load8(dy + o, v);
+          const unsigned tap = kh * 3 + kw;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if ((((j < 4 ? ar.x : ar.y) >> (8 * (j & 3))) & 255u) == tap) a[j] += v[j];
         }
       }
     }
-    ET<T>::st(dx + i, a);
+    store8(dx + ((long)b * n_in + n) * C + c0, a);
   }
 }
 
@@ -359,24 +379,36 @@ __global__ __launch_bounds__(256) void pos_encoding_kernel(int B, int Tn, int HW
 
 // rows[(b,to,ho,wo)][c*kt*kh*kw ...] of the stem convolution; clip is [B, Tc, Cc, H, W] fp32 (the module's input layout);
 // row width Kp >= Cc*KT*KH*KW, zero padded
+// A thread writes 8 consecutive columns of one row (one 16-byte store for bf16): the row's (b, to, ho, wo) and the first
+// column's (c, kt, kh, kw) are decoded once with 32-bit divisions, the other seven columns by carrying.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col3d_kernel(int B, int Tc, int Cc, int H, int W, int KT, int KH, int KW, int st, int sh, int sw,
                                                        int pt, int ph, int pw, int To, int Ho, int Wo, int Kp, const float* __restrict__ clip,
                                                        T* __restrict__ rows) {
-  const long total = (long)B * To * Ho * Wo * Kp;
+  const unsigned K8 = (unsigned)Kp / 8;
+  const unsigned total = (unsigned)B * To * Ho * Wo * K8;               // < 2^31 (checked by the launcher)
   const int K = Cc * KT * KH * KW;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int k = (int)(i % Kp);
-    const long row = i / Kp;
-    float v = 0.f;
-    if (k < K) {
-      const int kw = k % KW, kh = (k / KW) % KH, kt = (k / (KW * KH)) % KT, c = k / (KW * KH * KT);
-      const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho), to = (int)((row / ((long)Wo * Ho)) % To);
-      const long b = row / ((long)Wo * Ho * To);
-      const int t = to * st + kt - pt, h = ho * sh + kh - ph, w = wo * sw + kw - pw;
-      if (t >= 0 && t < Tc && h >= 0 && h < H && w >= 0 && w < W) v = clip[(((b * Tc + t) * Cc + c) * H + h) * W + w];
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const unsigned row = i / K8, k0 = (i - row * K8) * 8;
+    const unsigned r1 = row / (unsigned)Wo, wo = row - r1 * Wo;
+    const unsigned r2 = r1 / (unsigned)Ho, ho = r1 - r2 * Ho;
+    const unsigned b = r2 / (unsigned)To, to = r2 - b * To;
+    const unsigned q1 = k0 / (unsigned)KW;
+    int kw = (int)(k0 - q1 * KW);
+    const unsigned q2 = q1 / (unsigned)KH;
+    int kh = (int)(q1 - q2 * KH);
+    int c = (int)(q2 / (unsigned)KT), kt = (int)(q2 - (unsigned)c * KT);
+    const int t0 = (int)to * st - pt, h0 = (int)ho * sh - ph, w0 = (int)wo * sw - pw;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 + kt, h = h0 + kh, w = w0 + kw;
+      v[j] = 0.f;
+      if ((int)k0 + j < K && t >= 0 && t < Tc && h >= 0 && h < H && w >= 0 && w < W)
+        v[j] = clip[((((long)b * Tc + t) * Cc + c) * H + h) * W + w];
+      if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; if (++kt == KT) { kt = 0; ++c; } } }
     }
-    ET<T>::st(rows + i, v);
+    store8(rows + (long)row * Kp + k0, v);
   }
 }
 
@@ -686,9 +718,10 @@ extern "C" int vtx_pool_conv_ln_bwd(const vtx_pool_desc* d, const void* dy, cons
 }
 
 extern "C" int vtx_maxpool_skip_fwd(int dtype, int B, int T, int H, int W, int C, const void* x, void* y, uint8_t* arg, void* stream) {
-  VTX_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && x && y && arg, VTX_EINVAL, "maxpool_skip_fwd: bad arguments");
+  VTX_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && x && y && arg, VTX_EINVAL, "maxpool_skip_fwd: bad arguments (C must be a multiple of 8)");
   const int Ho = pooled(H, 2), Wo = pooled(W, 2);
-  const long total = (long)B * (1 + (long)T * Ho * Wo) * C;
+  VTX_REQUIRE((long)B * (1 + (long)T * H * W) * (C / 8) < (1L << 31), VTX_EINVAL, "maxpool_skip_fwd: tensor too large for the 32-bit index arithmetic");
+  const long total = (long)B * (1 + (long)T * Ho * Wo) * (C / 8);
   if (dtype == VTX_F32)
     hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, H, W, Ho, Wo, C, (const float*)x, (float*)y, arg);
   else
@@ -697,9 +730,10 @@ extern "C" int vtx_maxpool_skip_fwd(int dtype, int B, int T, int H, int W, int C
 }
 
 extern "C" int vtx_maxpool_skip_bwd(int dtype, int B, int T, int H, int W, int C, const void* dy, const uint8_t* arg, void* dx, void* stream) {
-  VTX_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && dy && dx && arg, VTX_EINVAL, "maxpool_skip_bwd: bad arguments");
+  VTX_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && dy && dx && arg, VTX_EINVAL, "maxpool_skip_bwd: bad arguments (C must be a multiple of 8)");
   const int Ho = pooled(H, 2), Wo = pooled(W, 2);
-  const long total = (long)B * (1 + (long)T * H * W) * C;
+  VTX_REQUIRE((long)B * (1 + (long)T * H * W) * (C / 8) < (1L << 31), VTX_EINVAL, "maxpool_skip_bwd: tensor too large for the 32-bit index arithmetic");
+  const long total = (long)B * (1 + (long)T * H * W) * (C / 8);
   if (dtype == VTX_F32)
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, H, W, Ho, Wo, C, (const float*)dy, arg, (float*)dx);
   else
@@ -723,7 +757,8 @@ extern "C" int vtx_im2col3d(int dtype, int B, int T, int C, int H, int W, const 
   VTX_REQUIRE(B > 0 && T > 0 && C > 0 && H > 0 && W > 0 && k3 && s3 && p3 && clip && rows, VTX_EINVAL, "im2col3d: bad arguments");
   VTX_REQUIRE(Kp >= C * k3[0] * k3[1] * k3[2] && Kp % 8 == 0, VTX_EINVAL, "im2col3d: row width must cover C*kt*kh*kw and be a multiple of 8");
   const int To = (T + 2 * p3[0] - k3[0]) / s3[0] + 1, Ho = (H + 2 * p3[1] - k3[1]) / s3[1] + 1, Wo = (W + 2 * p3[2] - k3[2]) / s3[2] + 1;
-  const long total = (long)B * To * Ho * Wo * Kp;
+  VTX_REQUIRE((long)B * To * Ho * Wo * (Kp / 8) < (1L << 31), VTX_EINVAL, "im2col3d: tensor too large for the 32-bit index arithmetic");
+  const long total = (long)B * To * Ho * Wo * (Kp / 8);
   if (dtype == VTX_F32)
     hipLaunchKernelGGL(im2col3d_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), B, T, C, H, W, k3[0], k3[1], k3[2], s3[0], s3[1], s3[2],
                        p3[0], p3[1], p3[2], To, Ho, Wo, Kp, clip, (float*)rows);

@@ -344,9 +344,8 @@ def single_run(argv=None):
     torch.cuda.set_device(device)
     force_comm = os.environ.get('VTX_FORCE_DP', '0') == '1'     # a 1-rank RCCL group: the whole exchange path on one GPU
     if (world > 1 or force_comm) and not dist.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', str(_free_port()))
-        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+        from vtx import dp as _dp
+        _dp.init_process_group(device, rank, world)
 
     # linear learning rate scale (model_pretrain.py:158-164): per-GPU batch x number of GPUs / 256
     effective_batch_size = args.batch_size * (world if under_launcher else max(num_gpus, 1))

@@ -45,8 +45,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
 
     def forward(self, x, res=None):
-        h = F_.LinearActResFn.apply(x, self.fc1.weight, self.fc1.bias, True, None)
-        return F_.LinearActResFn.apply(h, self.fc2.weight, self.fc2.bias, False, res)
+        return F_.MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, res)
 
 
 class MultiScaleAttention(nn.Module):

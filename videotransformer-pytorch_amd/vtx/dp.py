@@ -149,3 +149,33 @@ def broadcast_parameters(module, src=0, group=None):
 def shard_clips(global_batch, rank, world):
     """Clips are the independent units: rank r takes clips r, r+world, ... of the global batch."""
     return list(range(rank, global_batch, world))
+
+
+
+def init_process_group(device, rank=0, world=1, attempts=8):
+    """torch.distributed (RCCL) process group for one rank per GPU on a single node.  With more than one rank the launcher's
+    MASTER_ADDR / MASTER_PORT are used as they are.  A ONE-rank group (VTX_FORCE_DP=1: the DP code path on one GPU) needs no
+    agreement with anybody about the port: it takes a free one itself and, because "free when probed" is not "free when the
+    store binds it" (RCCL bootstrap sockets of an earlier group, another process), retries with another port on EADDRINUSE."""
+    import os
+    import socket
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world > 1:
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+        return
+    last = None
+    for _ in range(attempts):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ['MASTER_PORT'] = str(port)
+        try:
+            dist.init_process_group('nccl', device_id=device, rank=0, world_size=1)
+            return
+        except Exception as e:                       # DistNetworkError (EADDRINUSE) from the TCP store: another port
+            if 'EADDRINUSE' not in str(e) and 'address already in use' not in str(e).lower():
+                raise
+            last = e
+    raise last

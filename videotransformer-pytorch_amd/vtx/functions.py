@@ -1152,11 +1152,9 @@ class PosEncodingFn(torch.autograd.Function):
         N1 = 1 + T * HW
         dx = dy[:, 1:].contiguous()
         d_cls = ops.reduce_rows(dy, 1, B, Cn, Cn, 0, N1, 0)                                  # sum_b dy[b, 0]
-        d_sp = torch.empty(HW, Cn, dtype=torch.float32, device=dy.device)
-        d_tp = torch.empty(T, Cn, dtype=torch.float32, device=dy.device)
-        for b in range(B):
-            ops.reduce_rows(dy, HW, T, Cn, Cn, b * N1 + 1, HW, 1, out=d_sp, accumulate=b > 0)     # sum_t dy[b, 1 + t*HW + hw]
-            ops.reduce_rows(dy, T, HW, Cn, Cn, b * N1 + 1, 1, HW, out=d_tp, accumulate=b > 0)     # sum_hw
+        dE = ops.reduce_rows(dy, T * HW, B, Cn, Cn, 1, N1, 1)                                # [T*HW, C] fp32: sum_b dy[b, 1 + n]
+        d_sp = ops.reduce_rows(dE, HW, T, Cn, Cn, 0, HW, 1)                                  # sum_t dE[t*HW + hw]
+        d_tp = ops.reduce_rows(dE, T, HW, Cn, Cn, 0, 1, HW)                                  # sum_hw
         return dx, d_cls.reshape(cls_s), d_cls.clone().reshape(pc_s), d_sp.reshape(sp_s), d_tp.reshape(tp_s)
 
 
@@ -1242,3 +1240,50 @@ class LinearActResFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         ops.gemm_nt(dz, wT, dx, M, K, N)
         return dx, d_w, d_b, None, (dy.reshape(x.shape[:-1] + (N,)) if has_res else None)
+
+
+class MlpFn(torch.autograd.Function):
+    """y = fc2(GELU(fc1(x))) (+ res): the MViT Mlp as one function.  fc1 writes GELU(h) and GELU'(h) from one evaluation
+    (vtx_gemm_nt act = 2), the backward's input-gradient GEMM of fc2 multiplies by the stored derivative in its epilogue
+    (as FFNFn does for the TimeSformer block): no separate GELU-gradient pass over the [M, hidden] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res):
+        x = _chk(x)
+        K = x.shape[-1]
+        M = x.numel() // K
+        Hd, N = w1.shape[0], w2.shape[0]
+        need_t = any(ctx.needs_input_grad)
+        w1c, w1T = weights(w1, x.dtype, need_t)
+        w2c, w2T = weights(w2, x.dtype, need_t)
+        g = _empty((M, Hd), x)
+        gp = _empty((M, Hd), x)
+        ops.gemm_nt(x, w1c, g, M, Hd, K, bias=b1, act=2, C2=gp)
+        y = _empty((M, N), x)
+        if res is not None:
+            res = _chk(res)
+        ops.gemm_nt(g, w2c, y, M, N, Hd, bias=b2, R=res)
+        ctx.save_for_backward(x, g, gp, *[t for t in (w1T, w2T) if t is not None])
+        ctx.cfg = (b1 is not None, b2 is not None, res is not None, Hd, N)
+        return y.reshape(tuple(x.shape[:-1]) + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, gp, w1T, w2T = ctx.saved_tensors
+        has_b1, has_b2, has_res, Hd, N = ctx.cfg
+        K = x.shape[-1]
+        M = x.numel() // K
+        dy = _chk(dy).reshape(M, N)
+        if has_b2:
+            d_w2, d_b2 = ops.gemm_tn(dy, g, M, N, Hd, want_colsum=True)
+        else:
+            d_w2, d_b2 = ops.gemm_tn(dy, g, M, N, Hd), None
+        dh = _empty((M, Hd), x)
+        ops.gemm_nt(dy, w2T, dh, M, Hd, N, dgelu_in=gp, dgelu_kind=1)
+        if has_b1:
+            d_w1, d_b1 = ops.gemm_tn(dh, x, M, Hd, K, want_colsum=True)
+        else:
+            d_w1, d_b1 = ops.gemm_tn(dh, x, M, Hd, K), None
+        dx = torch.empty_like(x)
+        ops.gemm_nt(dh, w1T, dx, M, K, Hd)
+        return dx, d_w1, d_b1, d_w2, d_b2, (dy.reshape(x.shape[:-1] + (N,)) if has_res else None)
