@@ -64,7 +64,19 @@ def build_variant(name, defines):
 
 
 def build(force=False, verbose=True):
+    """Compile what is stale and link.  Serialised across processes by a file lock: N ranks of a multi-GPU launch may all
+    find the library stale at the same moment (a fresh copy of the tree) and must not write the same objects concurrently."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in res]
