@@ -423,6 +423,72 @@ def test_gemm_nt_pp_continuous_flow(N, K, vtx_opts):
         assert torch.equal(C, first)
 
 
+@pytest.mark.parametrize('K', [192, 768])
+def test_gemm_nt_pp_lean_passes(K, vtx_opts):
+    """Lean epilogue passes of the continuous-flow kernels (scalar store base + 32-bit lane offset, software-pipelined LDS
+    staging, row scales through ds_bpermute) against the general passes of the same kernels (pp_epi=4): bit-identical for
+    every fused epilogue; row maps whose group boundary falls INSIDE a 16-row pass (closed form and table form), full and
+    ragged tiles, split rows (general passes inside a lean launch); and against the float64 reference."""
+    from vtx import ops
+    dtype = torch.bfloat16
+    vtx_opts('gemm_nt', 'pp256')
+    vtx_opts('pp_cont', '1')
+    N, grp, skip, G = 512, 300, 3, 9                # 2700 logical rows; group boundaries at local rows 44, 88, 132, ... of their tiles
+    M = grp * G
+    phys = M + skip * G + 1
+    X, W, bias = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
+    Xd, Wd, bd = dev(X, dtype), dev(W, dtype), dev(bias)
+    full = q(X, dtype) @ q(W, dtype).t() + bias.double()
+    cm = ops.rowmap(grp, skip, 1)
+    rows = torch.arange(M) + 1 + (torch.arange(M) // grp) * skip                      # physical row of every logical row
+    tab_vals = [5 * g for g in range(G)] + [5 * G]                                    # table form: m + 5 * (m // grp), one spare entry
+    tab = ops.upload_i32(tab_vals, DEV)
+    tmap = ops.tabmap(grp, tab, 5)
+    trows = torch.arange(M) + (torch.arange(M) // grp) * 5
+    R = rnd(phys + 5 * G, N, seed=6)
+    Rd, Rq = dev(R, dtype), q(R, dtype)
+    Hm = rnd(M, N, seed=8)
+    sv = (torch.rand(M // 4, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7
+    svr = sv.double().repeat_interleave(4)[:, None]
+
+    def run(**kw):
+        outs = []
+        for epi in ('0', '4'):
+            vtx_opts('pp_epi', epi)
+            C = torch.zeros(phys + 5 * G, N, dtype=dtype, device=DEV)
+            C2 = torch.zeros(M, N, dtype=dtype, device=DEV)
+            if kw.get('act'):
+                ops.gemm_nt(Xd, Wd, C, M, N, K, C2=C2, **kw)
+            else:
+                ops.gemm_nt(Xd, Wd, C, M, N, K, **kw)
+            outs.append((C, C2))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), f'lean passes differ: {sorted(kw)} K={K}'
+        return outs[0][0].float().cpu(), outs[0][1].float().cpu()
+
+    for grid in ('256', '8'):
+        vtx_opts('pp_grid', grid)
+        c, _ = run(bias=bd, cmap=cm)
+        check(f'lean plain map K={K}', c[rows], full, 1e-2)
+        untouched = torch.ones(c.shape[0], dtype=torch.bool)
+        untouched[rows] = False
+        assert not c[untouched].any(), 'a skipped physical row was written'
+        c, _ = run(bias=bd, cmap=tmap)
+        check(f'lean plain table K={K}', c[trows], full, 1e-2)
+        c, _ = run(bias=bd, cmap=cm, row_scale=dev(sv), rs=(4, 1, 1, 0))
+        check(f'lean scale map K={K}', c[rows], full * svr, 1e-2)
+        c, _ = run(bias=bd, cmap=cm, R=Rd, rmap=cm)
+        check(f'lean residual map K={K}', c[rows], full + Rq[rows], 1e-2)
+        c, _ = run(bias=bd, cmap=tmap, R=Rd, rmap=tmap, row_scale=dev(sv), rs=(4, 1, 1, 0))
+        check(f'lean residual+scale table K={K}', c[trows], full * svr + Rq[trows], 1e-2)
+        c, _ = run(dgelu_in=dev(Hm, dtype), dgelu_kind=1)
+        check(f'lean multiplier K={K}', c[:M], (q(X, dtype) @ q(W, dtype).t()) * q(Hm, dtype), 1e-2)
+        pre = full.clone().requires_grad_(True)
+        torch.nn.functional.gelu(pre).sum().backward()
+        c, c2 = run(bias=bd, act=2)
+        check(f'lean gelu K={K}', c[:M], torch.nn.functional.gelu(full), 1e-2)
+        check(f"lean gelu' K={K}", c2, pre.grad, 1e-2)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N1,N2', [(1000, 256, 128), (3136, 768, 768), (500, 216, 768), (70, 8, 2304), (12552, 768, 768),
                                      (1031, 216, 768), (4099, 3072, 768), (1024, 8, 136), (4131, 1024, 1280)])

@@ -141,6 +141,20 @@ __device__ inline void dma16_nt(const bf16raw* src, bf16raw* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 }
 
+// A 16-byte nontemporal store at a SCALAR base + a 32-bit lane offset (global_store_dwordx4 voffset, data, saddr).  The base
+// passes through an empty asm as in issue() below: hipcc otherwise folds base + offset into a per-lane 64-bit pointer.
+__device__ inline void st16_nt_s(const char* sbase, unsigned voff, u32x4 v) {
+  asm volatile("" : "+s"(sbase));
+  typedef __attribute__((address_space(1))) u32x4 g_u32x4;       // (the empty asm hides the pointer's origin: name the address space,
+  __builtin_nontemporal_store(v, (g_u32x4*)(sbase + voff));      //  or the store becomes a FLAT one, which also counts on lgkmcnt)
+}
+__device__ inline u32x4 pack8(const float (&v)[8]) {          // eight floats -> eight bf16 (v_cvt_pk_bf16_f32, round to nearest even)
+  union { bf16x8 b; u32x4 u; } o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.b[i] = (__bf16)v[i];
+  return o.u;
+}
+
 __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_dma_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, EpiParams ep) {
@@ -492,10 +506,14 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     const int bl = am.fast ? am.bound - m0s : 0x7fffffff;    // local row at which the skip starts
     const unsigned lda2 = (unsigned)lda * 2u, ldb2 = (unsigned)ldb * 2u;
     const int nl = min(N - 1 - n0s, PP_BN - 1);               // last valid local column (ragged last column tile)
+    // (the lane's row / chunk terms are recomputed per call from an opaque copy of the lane id: hoisted out of the tile loop
+    // they are eight more registers live through the main loop -- the ones hipcc spilled first)
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                // this wave owns pieces 2*wave, 2*wave+1 (8 region rows each)
-      const int rho = (wave * 2 + j) * 8 + (lane >> 3);
-      const unsigned c2 = (unsigned)(((lane & 7) ^ ((rho >> 1) & 7)) * 16);
+      const int rho = (wave * 2 + j) * 8 + (lq >> 3);
+      const unsigned c2 = (unsigned)(((lq & 7) ^ ((rho >> 1) & 7)) * 16);
       const int la0 = min((rho >> 6) * 128 + (rho & 63), ml), la1 = min((rho >> 6) * 128 + (rho & 63) + 64, ml);
       const int lb0 = min((rho >> 5) * 64 + (rho & 31), nl), lb1 = min((rho >> 5) * 64 + (rho & 31) + 32, nl);
       unsigned ra0, ra1;
@@ -826,20 +844,37 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       //   accumulators, so it goes through LDS: 16 LDS-DMA pieces into the wave's slice of the (idle) operand
       //   ring.  The next tile's prologue then has to wait for the passes to finish reading it (one extra
       //   barrier; ~1.5 us of prologue latency exposed instead of ~10 us of store latency).
-      const int en = en0 + (lane & 7) * 8;
+      // an opaque copy of the lane id for everything below: the epilogue's lane constants (staging / block read addresses, row and
+      // column of the lane, ...) are then recomputed per tile -- some twenty vector instructions -- instead of being hoisted out
+      // of the tile loop and kept in registers through the main loop (which spilled once the lean passes were added)
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int en = en0 + (le & 7) * 8;
       const bool col_ok = en < ep.N;
       const int enc = col_ok ? en : 0;
-      const int er = em0 + (lane >> 3);            // row of pass p, half-row u: er + 16 p + 8 u
+      const int er = em0 + (le >> 3);            // row of pass p, half-row u: er + 16 p + 8 u
       constexpr bool HAS_PRE = PRE != PRE_NONE, pre_res = PRE == PRE_RES;
-      bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: lane-linear per piece
+      bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: le-linear per piece
       const int tile_m0 = em0 - wr * 128;          // first row of the whole 256-row tile (wave-uniform)
+      const TileMap cm = make_tile_map(ep.cmap, tile_m0);
+      const unsigned ldcb = (unsigned)ep.ldc * 2u;                     // bytes per C row
+      const long skipb64 = (long)cm.skip * (long)ldcb;
+      bool lean = CONT && dbg == 0 && em0 + 127 < ep.M && en0 + 63 < ep.N && (ep.split_row <= 0 || em0 + 127 < ep.split_row) &&
+                  cm.fast && cm.skip >= 0 && skipb64 < (1L << 30) && ep.ldc < (1L << 22) && PRE != PRE_DGELU;
+      if constexpr (HAS_ACT) lean = lean && ep.act == 2 && ep.ldc2 < (1L << 22);
+      // first physical row of the wave's block, and the local row from which the map's skip applies (none if the whole
+      // block lies behind the boundary: the skip is in the base then)
+      const int lean_lb = em0 < cm.bound ? cm.bound - em0 : 0x7fffffff;
+      const char* const lean_cb = reinterpret_cast<const char*>(ep.C) +
+                                  ((cm.base_q + em0 + (em0 >= cm.bound ? (long)cm.skip : 0L)) * ep.ldc + en0) * 2;
+      const unsigned lean_skipb = (unsigned)skipb64;
       if constexpr (HAS_PRE && !PF) {
         const bf16raw* const pre_base = reinterpret_cast<const bf16raw*>(pre_res ? ep.R : ep.dgelu_in);
         const long pre_ld = pre_res ? ep.ldr : ep.ld_dgelu;
         const TileMap rm = make_tile_map(ep.rmap, tile_m0);
         const int row_last = ep.M - 1;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {             // piece j = rows 8j .. 8j+7 of the block; lane -> row 8j + lane/8, chunk lane%8
+        for (int j = 0; j < 16; ++j) {             // piece j = rows 8j .. 8j+7 of the block; le -> row 8j + le/8, chunk le%8
           int ml = er + 8 * j;
           const bool past = ml > row_last;         // always-valid addresses; only the stores are predicated
           if (past) ml = row_last;
@@ -851,8 +886,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           dma16(pre_base + rr * pre_ld + enc, pre_lds + j * 512);
         }
       }
-      // bias in the ACCUMULATOR layout (a lane owns one column of each 32-column half: 2 registers instead of the 8 a
-      // row-vector lane needs, and 64 adds per tile instead of 128); same fp32 add, same result
+      // bias in the ACCUMULATOR layout (a le owns one column of each 32-column half: 2 registers instead of the 8 a
+      // row-vector le needs, and 64 adds per tile instead of 128); same fp32 add, same result
       float bcol[2] = {0.f, 0.f};
       if (ep.bias) {
         if constexpr (CF) {                        // landed in the staging slice during K tile 0 (see above)
@@ -861,14 +896,22 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         } else {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
-            const int c = en0 + ni * 32 + (lane & 31);
+            const int c = en0 + ni * 32 + (le & 31);
             bcol[ni] = ep.bias[c < ep.N ? c : 0];
           }
         }
       }
       float sc[8][2];
+      // lean passes: the 128 row scales of the wave's block stay in TWO registers (le l: rows l and 64 + l); a pass fetches its
+      // two values per le with ds_bpermute_b32 (no LDS storage: the staging slice is full) inside its read batch
+      float scl[2] = {0.f, 0.f};
       if constexpr (HAS_SC && CF) {                // landed in the staging slice during K tile 0: row r of the block at word 128 + r
-        const unsigned sc_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 512 + (lane >> 3) * 4);
+        if (lean) {
+          const unsigned scl_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 512 + le * 4);
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(scl[0]), "=&v"(scl[1]) : "v"(scl_rd) : "memory");
+        } else {
+        const unsigned sc_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) + 512 + (le >> 3) * 4);
         asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:32\n\tds_read_b32 %2, %16 offset:64\n\t"
                      "ds_read_b32 %3, %16 offset:96\n\tds_read_b32 %4, %16 offset:128\n\tds_read_b32 %5, %16 offset:160\n\t"
                      "ds_read_b32 %6, %16 offset:192\n\tds_read_b32 %7, %16 offset:224\n\tds_read_b32 %8, %16 offset:256\n\t"
@@ -879,19 +922,25 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
                        "=&v"(sc[3][0]), "=&v"(sc[3][1]), "=&v"(sc[4][0]), "=&v"(sc[4][1]), "=&v"(sc[5][0]), "=&v"(sc[5][1]),
                        "=&v"(sc[6][0]), "=&v"(sc[6][1]), "=&v"(sc[7][0]), "=&v"(sc[7][1])
                      : "v"(sc_rd) : "memory");
+        }
       }
       if constexpr (HAS_SC && !CF) {
+        auto scale_of = [&](int ml) -> float {
+          if (ml >= ep.M) ml = ep.M - 1;
+          const bool split = ep.split_row > 0 && ml >= ep.split_row;
+          const unsigned q1 = fast_div((unsigned)ml, ep.rs_magic1, ep.rs_shift1);
+          const unsigned q2 = fast_div((unsigned)ml, ep.rs_magic2, ep.rs_shift2);
+          return ep.row_scale[split ? (ml - ep.split_row) : (int)q1 * ep.rs_m1 + (ml - (int)q2 * ep.rs_d2) * ep.rs_m2];
+        };
+        if (lean) {
+          scl[0] = scale_of(em0 + le);
+          scl[1] = scale_of(em0 + 64 + le);
+        } else {
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+          for (int p = 0; p < 8; ++p)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            int ml = er + 16 * p + 8 * u;
-            if (ml >= ep.M) ml = ep.M - 1;
-            const bool split = ep.split_row > 0 && ml >= ep.split_row;
-            const unsigned q1 = fast_div((unsigned)ml, ep.rs_magic1, ep.rs_shift1);
-            const unsigned q2 = fast_div((unsigned)ml, ep.rs_magic2, ep.rs_shift2);
-            sc[p][u] = ep.row_scale[split ? (ml - ep.split_row) : (int)q1 * ep.rs_m1 + (ml - (int)q2 * ep.rs_d2) * ep.rs_m2];
-          }
+            for (int u = 0; u < 2; ++u) sc[p][u] = scale_of(er + 16 * p + 8 * u);
+        }
       }
       if constexpr (!CF) {
         if (more && tid == 0) pending = atomicAdd(my_ctr, 1);
@@ -904,6 +953,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         if constexpr (HAS_SC) {
 #pragma unroll
           for (int p = 0; p < 8; ++p) { asm volatile("" : "+v"(sc[p][0])); asm volatile("" : "+v"(sc[p][1])); }
+          asm volatile("" : "+v"(scl[0])); asm volatile("" : "+v"(scl[1]));
         }
         if constexpr (!HAS_PRE) {
           if (more) { set_tile(t, 0); m0 = m0s; n0 = n0s; prologue(); }   // ring is free: the next tile's first 7 regions land under the passes
@@ -913,23 +963,22 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         }
       }
       stamp(5);
-      const TileMap cm = make_tile_map(ep.cmap, tile_m0);
       // The staged rows (and the residual rows) are read back with inline-asm ds_read + lgkmcnt(0) in ONE statement:
       // hipcc orders any ds_read IT emits behind every LDS-DMA in flight (`s_waitcnt vmcnt(0)`), i.e. pass 0 would
       // wait for the 14 prologue requests issued just above.
       const unsigned stg_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) +
-                                                                    ((lane >> 3) * PP_STG_LD + (lane & 7) * 8) * 4);
-      const unsigned pre_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(pre_lds) + lane * 16);
+                                                                    ((le >> 3) * PP_STG_LD + (le & 7) * 8) * 4);
+      const unsigned pre_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(pre_lds) + le * 16);
       // residual-block flow: pass p reads this wave's 2 KB of ring region p (buffer pa for p < 4, the other one after)
-      const unsigned pf_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(lds + wave * 1024) + lane * 16);
+      const unsigned pf_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(lds + wave * 1024) + le * 16);
       const int pa = (nk & 1) ^ par;
 #define PP_EPI2(p_, mi_, half_)                                                                         \
       {                                                                                                 \
-        const int col = lane & 31, rhalf = (lane >> 5) * 4;                                             \
+        const int col = le & 31, rhalf = (le >> 5) * 4;                                             \
         if (dbg != 3) {                                                                                 \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)  \
             stg[((r & 3) + 8 * (r >> 2) + rhalf) * PP_STG_LD + ni * 32 + col] = acc[mi_][ni][8 * (half_) + r] + bcol[ni]; \
-        } else { stg[lane] = acc[mi_][0][8 * (half_)] + acc[mi_][1][8 * (half_) + 7]; }                 \
+        } else { stg[le] = acc[mi_][0][8 * (half_)] + acc[mi_][1][8 * (half_) + 7]; }                 \
         lgkm0();                                                                                        \
         __builtin_amdgcn_wave_barrier();                                                                \
         f32x4 s00, s01, s10, s11;                                                                       \
@@ -1001,21 +1050,179 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       // Plain epilogue (nothing to read, no activation, no row scale: result = bf16(acc + bias)): the pass stages PAIRS OF
       // ROWS as packed bf16 -- registers 2k, 2k+1 of an accumulator are the same column of two adjacent rows, so one
       // v_cvt_pk_bf16_f32 + one ds_write_b32 stage two elements -- instead of fp32 words: 8 LDS writes and 2 LDS reads
-      // per lane and pass instead of 16 and 4 (the fp32 staging moved 512 KB through the LDS per tile, ~2.3 us of the
-      // 4.7 us the eight passes of a plain tile take, most of it on the 64-B-per-clock ds_write_b32 path).  A lane then
-      // holds rows 2p, 2p+1 (p = lane / 8) of 8 columns as 8 words {row 2p | row 2p+1}: eight v_perm_b32 separate them.
-      // Row-pair r sits at word r * 64 + 4 * ((r >> 1) & 1) + 8 * (r >> 2): the 4-word shift keeps the 16-lane groups of the
+      // per le and pass instead of 16 and 4 (the fp32 staging moved 512 KB through the LDS per tile, ~2.3 us of the
+      // 4.7 us the eight passes of a plain tile take, most of it on the 64-B-per-clock ds_write_b32 path).  A le then
+      // holds rows 2p, 2p+1 (p = le / 8) of 8 columns as 8 words {row 2p | row 2p+1}: eight v_perm_b32 separate them.
+      // Row-pair r sits at word r * 64 + 4 * ((r >> 1) & 1) + 8 * (r >> 2): the 4-word shift keeps the 16-le groups of the
       // ds_read_b128 on 64 distinct banks, the 8-word one keeps row-pair 3's shifted tail off row-pair 4.  Same value, same rounding (one fp32 add, one round-to-nearest-even) as the fp32 staging.
       constexpr bool PAIRS = VTX_PP_BF16_STAGE && PRE == PRE_NONE && !HAS_SC && !HAS_ACT;
-      if constexpr (PAIRS) {
+      // Lean passes (round 4).  Wave-uniform test per tile: the wave's whole 128 x 64 block lies inside M x N, none of its rows
+      // is a split row, the C row map is in tile form (at most one group boundary inside the tile) and its skip fits 30 bits
+      // of bytes.  Then (a) a store address is a SCALAR base (first row of the pass, s_add per pass) + a 32-bit le offset
+      // (global_store saddr form): no predicate, no branch, three vector instructions per row where the general pass above
+      // spends ~45 (64-bit multiplies, the split / table / slow-map branches); (b) every LDS access of a pass is inline asm
+      // with a known instruction count, which lets the passes run as a software pipeline on ONE staging buffer and ONE
+      // register set: the LDS executes a wave's instructions in issue order, so W(p+1) may be issued right behind R(p) with no
+      // wait in between, and the wait in front of F(p) is lgkmcnt(<number of W instructions>): R(p)'s latency is covered by
+      // the issue of W(p+1), W(p+1)'s by F(p)'s arithmetic and stores.
+      //     W(0) R(0) | W(1) wait F(0) R(1) | W(2) wait F(1) R(2) | ... | W(7) wait F(6) R(7) | wait F(7)
+      // Same values in the same order as the general passes (bit-identical: tests/test_gpu_kernels.py::test_gemm_nt_pp_lean_passes).
+      const unsigned stg_wr0 = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg)) ;
+#define PP_LWAIT(n_, ...) asm volatile("s_waitcnt lgkmcnt(%[cnt])" : __VA_ARGS__ : [cnt] "n"(n_) : "memory"); __builtin_amdgcn_sched_barrier(0)
+      if (lean) {
+        int ln = le;                               // opaque copy: the le constants below are recomputed per tile (a dozen vector
+        asm volatile("" : "+v"(ln));                 // instructions) instead of living in registers through the main loop
+        if constexpr (PAIRS) {
+          // staging words as in PP_EPI2B: le (col, hi) writes row pairs 2 hi + {0, 1, 4, 5} at word 132 hi + {0, 64, 264, 328} + 32 ni + col
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+          const int p2 = ln >> 3;
+          const unsigned wa0 = stg_wr0 + (unsigned)(((ln >> 5) * 132 + (ln & 31)) * 4), wa1 = wa0 + 264 * 4;
+          const unsigned pair_rd = stg_wr0 + (unsigned)((p2 * 64 + 4 * ((p2 >> 1) & 1) + 8 * (p2 >> 2) + (ln & 7) * 8) * 4);
+          const unsigned v0 = (unsigned)(2 * p2) * ldcb + (unsigned)(ln & 7) * 16u;
+          u32x4 w0, w1;
+#define PP_LW(mi_, half_)                                                                               \
+          {                                                                                             \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) { \
+              union { bf16x2 v; unsigned u; } x, y;  /* row pairs 2 hi + 4 kk (registers 4 kk, 4 kk + 1) and + 1 (4 kk + 2, + 3) */ \
+              x.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk] + bcol[ni]);                         \
+              x.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 1] + bcol[ni]);                     \
+              y.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 2] + bcol[ni]);                     \
+              y.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 3] + bcol[ni]);                     \
+              if (ni == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"(kk ? wa1 : wa0), "v"(x.u), "v"(y.u) : "memory"); \
+              else asm volatile("ds_write2_b32 %0, %1, %2 offset0:32 offset1:96" :: "v"(kk ? wa1 : wa0), "v"(x.u), "v"(y.u) : "memory"); \
+            }                                                                                           \
+          }
+#define PP_LR() asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(w0), "=&v"(w1) : "v"(pair_rd) : "memory")
+#define PP_LF(p_)                                                                                       \
+          {                                                                                             \
+            const char* const base = lean_cb + (long)(16 * (p_)) * ldcb;                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
+              const unsigned sel = u ? 0x07060302u : 0x05040100u;                                       \
+              u32x4 o;                                                                                  \
+              o[0] = __builtin_amdgcn_perm(w0[1], w0[0], sel);                                          \
+              o[1] = __builtin_amdgcn_perm(w0[3], w0[2], sel);                                          \
+              o[2] = __builtin_amdgcn_perm(w1[1], w1[0], sel);                                          \
+              o[3] = __builtin_amdgcn_perm(w1[3], w1[2], sel);                                          \
+              const unsigned voff = v0 + (u ? ldcb : 0u) + ((2 * p2 + u >= lean_lb - 16 * (p_)) ? lean_skipb : 0u); \
+              st16_nt_s(base, voff, o);                                                                 \
+            }                                                                                           \
+          }
+          PP_LW(0, 0) PP_LR();
+          PP_LW(0, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(0) PP_LR();
+          PP_LW(1, 0) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(1) PP_LR();
+          PP_LW(1, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(2) PP_LR();
+          PP_LW(2, 0) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(3) PP_LR();
+          PP_LW(2, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(4) PP_LR();
+          PP_LW(3, 0) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(5) PP_LR();
+          PP_LW(3, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(6) PP_LR();
+          PP_LWAIT(0, "+v"(w0), "+v"(w1)); PP_LF(7)
+#undef PP_LW
+#undef PP_LR
+#undef PP_LF
+        } else {
+          // fp32 staging as in PP_EPI2: le (col, hi) writes rows 4 hi + {0, 1, 2, 3, 8, 9, 10, 11} at word 256 hi + {0, 64, 128, 192, 512, ...} + 32 ni + col
+          const unsigned wa0 = stg_wr0 + (unsigned)(((ln >> 5) * 256 + (ln & 31)) * 4), wa1 = wa0 + 512 * 4;
+          const unsigned vf0 = (unsigned)(ln >> 3) * ldcb + (unsigned)(ln & 7) * 16u;
+          const unsigned ldc2b = (unsigned)ep.ldc2 * 2u;               // second output (GELU'): identity row map
+          const unsigned vg0 = (unsigned)(ln >> 3) * ldc2b + (unsigned)(ln & 7) * 16u;
+          const char* const lean_c2b = reinterpret_cast<const char*>(ep.C2) + ((long)em0 * ep.ldc2 + en0) * 2;
+          f32x4 s00, s01, s10, s11;
+          u32x4 pre[2];
+          float scu[2] = {1.f, 1.f};                   // the pass's two row scales (rows le / 8 and + 8 of its 16)
+          const unsigned bp_addr = (unsigned)(ln >> 3) * 4u;
+#define PP_LW(mi_, half_)                                                                               \
+          {                                                                                             \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
+            _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2) {                                          \
+              const float x = acc[mi_][ni][8 * (half_) + 4 * kk + 2 * r2] + bcol[ni];                   \
+              const float y = acc[mi_][ni][8 * (half_) + 4 * kk + 2 * r2 + 1] + bcol[ni];               \
+              const unsigned wa = kk ? wa1 : wa0;                                                       \
+              if (ni == 0 && r2 == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"(wa), "v"(x), "v"(y) : "memory"); \
+              if (ni == 0 && r2 == 1) asm volatile("ds_write2_b32 %0, %1, %2 offset0:128 offset1:192" :: "v"(wa), "v"(x), "v"(y) : "memory"); \
+              if (ni == 1 && r2 == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset0:32 offset1:96" :: "v"(wa), "v"(x), "v"(y) : "memory"); \
+              if (ni == 1 && r2 == 1) asm volatile("ds_write2_b32 %0, %1, %2 offset0:160 offset1:224" :: "v"(wa), "v"(x), "v"(y) : "memory"); \
+            }                                                                                           \
+          }
+#define PP_LR(p_)                                                                                       \
+          if constexpr (HAS_PRE) {                                                                      \
+            const unsigned prd__ = PF ? pf_rd + (unsigned)((((p_) < 4 ? pa : pa ^ 1) * PP_BUF + ((p_) & 3) * PP_REGION) * 2) \
+                                      : pre_rd + 2 * (p_) * 1024;                                       \
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\t"                     \
+                         "ds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %6 offset:2064\n\t"       \
+                         "ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:1024"                       \
+                         : "=&v"(s00), "=&v"(s01), "=&v"(s10), "=&v"(s11), "=&v"(pre[0]), "=&v"(pre[1]) \
+                         : "v"(stg_rd), "v"(prd__) : "memory");                                         \
+          } else                                                                                        \
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"                     \
+                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:2064"           \
+                         : "=&v"(s00), "=&v"(s01), "=&v"(s10), "=&v"(s11) : "v"(stg_rd) : "memory");      \
+          if constexpr (HAS_SC)                        /* source le = block row mod 64, source register by the block half */ \
+            asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%4\n\tds_bpermute_b32 %1, %2, %3 offset:%5"   \
+                         : "=&v"(scu[0]), "=&v"(scu[1]) : "v"(bp_addr), "v"((p_) < 4 ? scl[0] : scl[1]),   \
+                           "n"(((16 * (p_)) & 63) * 4), "n"(((16 * (p_) + 8) & 63) * 4) : "memory")
+#define PP_LWAITF(n_)                                                                                   \
+          if constexpr (HAS_PRE) { PP_LWAIT(n_, "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11), "+v"(pre[0]), "+v"(pre[1]), "+v"(scu[0]), "+v"(scu[1])); } \
+          else { PP_LWAIT(n_, "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11), "+v"(scu[0]), "+v"(scu[1])); }
+#define PP_LF(p_)                                                                                       \
+          {                                                                                             \
+            _Pragma("clang fp contract(off)")        /* scale, then residual: two roundings as in the general passes (bit-identical) */ \
+            float v[2][8];                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+              v[0][j] = s00[j]; v[0][4 + j] = s01[j]; v[1][j] = s10[j]; v[1][4 + j] = s11[j];           \
+            }                                                                                           \
+            const char* const base = lean_cb + (long)(16 * (p_)) * ldcb;                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
+              if constexpr (HAS_ACT) {               /* GELU, second output = its derivative */        \
+                float gp[8];                                                                            \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) gelu_erf_both(v[u][j], v[u][j], gp[j]);   \
+                st16_nt_s(lean_c2b + (long)(16 * (p_)) * ldc2b, vg0 + (u ? 8u * ldc2b : 0u), pack8(gp)); \
+              }                                                                                         \
+              if constexpr (PRE == PRE_MUL) {        /* the block holds gelu'(x) itself */              \
+                const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+                  v[u][2 * j] *= __uint_as_float(w[j] << 16);                                           \
+                  v[u][2 * j + 1] *= __uint_as_float(w[j] & 0xffff0000u);                               \
+                }                                                                                       \
+              }                                                                                         \
+              if constexpr (HAS_SC) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[u][j] *= scu[u]; } \
+              if constexpr (pre_res) {               /* no split rows in a lean block */                \
+                const uint32_t w[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+                  v[u][2 * j] += __uint_as_float(w[j] << 16);                                           \
+                  v[u][2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);                               \
+                }                                                                                       \
+              }                                                                                         \
+              const unsigned voff = vf0 + (u ? 8u * ldcb : 0u) +                                        \
+                                    (((ln >> 3) + 8 * u >= lean_lb - 16 * (p_)) ? lean_skipb : 0u);   \
+              st16_nt_s(base, voff, pack8(v[u]));                                                       \
+            }                                                                                           \
+            if constexpr (PF) {                      /* region p_ is read (the wait above): it takes the next tile's operands */ \
+              if ((p_) < 7 && more) issue((p_) & 3, nk + ((p_) >> 2));                                  \
+            }                                                                                           \
+          }
+          PP_LW(0, 0) PP_LR(0);
+          PP_LW(0, 1) PP_LWAITF(8) PP_LF(0) PP_LR(1);
+          PP_LW(1, 0) PP_LWAITF(8) PP_LF(1) PP_LR(2);
+          PP_LW(1, 1) PP_LWAITF(8) PP_LF(2) PP_LR(3);
+          PP_LW(2, 0) PP_LWAITF(8) PP_LF(3) PP_LR(4);
+          PP_LW(2, 1) PP_LWAITF(8) PP_LF(4) PP_LR(5);
+          PP_LW(3, 0) PP_LWAITF(8) PP_LF(5) PP_LR(6);
+          PP_LW(3, 1) PP_LWAITF(8) PP_LF(6) PP_LR(7);
+          PP_LWAITF(0) PP_LF(7)
+#undef PP_LW
+#undef PP_LR
+#undef PP_LWAITF
+#undef PP_LF
+        }
+      } else if constexpr (PAIRS) {
         unsigned* const stgw = reinterpret_cast<unsigned*>(stg);
-        const int p2 = lane >> 3;
+        const int p2 = le >> 3;
         const unsigned pair_rd = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg) +
-                                                                       (p2 * 64 + 4 * ((p2 >> 1) & 1) + 8 * (p2 >> 2) + (lane & 7) * 8) * 4);
+                                                                       (p2 * 64 + 4 * ((p2 >> 1) & 1) + 8 * (p2 >> 2) + (le & 7) * 8) * 4);
         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #define PP_EPI2B(p_, mi_, half_)                                                                        \
         {                                                                                               \
-          const int col = lane & 31, hi = lane >> 5;                                                    \
+          const int col = le & 31, hi = le >> 5;                                                    \
           _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int k = 0; k < 4; ++k) { \
             /* registers 2k, 2k+1 of this half: rows {0,2,8,10}[k] + 4 hi (+1) of the pass's 16 */     \
             const int rp = ((2 * k) & 3) / 2 + 4 * ((2 * k) >> 2) + 2 * hi;                             \
@@ -1054,6 +1261,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
         PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
       }
+#undef PP_LWAIT
 #undef PP_EPI2
       stamp(6);
       if constexpr (HAS_PRE && !PF) {
@@ -1070,7 +1278,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           // out (rows em0 + 8 g + [0, 8), g = 0 .. 15; a store with an empty execution mask is not issued); the timeline and
           // the store-free diagnostic mode add or drop vector memory operations
           const bool second = !HAS_ACT || ep.act == 2 || ep.C2 != nullptr;
-          relax = em0 + 120 < ep.M && en0 < ep.N && second && trace == nullptr && dbg == 0 && nk >= 3;
+          relax = em0 + 120 < ep.M && en0 < ep.N && second && trace == nullptr && (dbg == 0 || dbg == 4) && nk >= 3;
         }
         m0 = m0s; n0 = n0s;
         par ^= nk & 1;

@@ -15,8 +15,30 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of S byt
 bound by 2*(7/8)*S / link rate, so buckets are large (one layer, ~40 MB fp32) rather
 than torch DDP's NVSwitch-era 25 MB default.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _host_side(group, t):
+    """True when the group's backend cannot take a device tensor as it is: anything but RCCL (gloo: the two-ranks-on-one-GPU
+    tests, a debug rendezvous without xGMI).  Such collectives are staged through pinned host memory."""
+    return t.is_cuda and dist.get_backend(group) != 'nccl'
+
+
+def all_reduce_sum(t, group=None):
+    """Blocking sum all-reduce of a (device) tensor on whatever backend the group has."""
+    if _host_side(group, t):
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()      # h is freed on return
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
 
 
 class GradBuckets:
@@ -94,6 +116,16 @@ class GradBuckets:
             b['comm'] = buf.to(self.comm_dtype)
             buf = b['comm']
         op = dist.ReduceOp.AVG if dist.get_backend(self.group) == 'nccl' else dist.ReduceOp.SUM
+        b['host'] = None
+        if _host_side(self.group, buf):
+            # not RCCL: the bucket travels through pinned host memory.  The kernels that wrote it are on the current stream:
+            # the copy follows them there, and the host waits for the copy before the backend's threads read the buffer.
+            if b.get('pinned') is None or b['pinned'].shape != buf.shape or b['pinned'].dtype != buf.dtype:
+                b['pinned'] = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+            b['host'] = b['pinned']
+            b['host'].copy_(buf, non_blocking=True)
+            torch.cuda.current_stream(buf.device).synchronize()
+            buf = b['host']
         b['handle'] = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
         b['avg_in_op'] = op == dist.ReduceOp.AVG
         self._launched.append(b)
@@ -113,6 +145,8 @@ class GradBuckets:
         """Wait for every bucket's all-reduce; afterwards param.grad holds the mean gradient."""
         for b in self._launched:
             b['handle'].wait()
+            if b.get('host') is not None:
+                (b['comm'] if b['comm'] is not None else b['flat']).copy_(b['host'], non_blocking=True)
             if b['comm'] is not None:
                 b['flat'].copy_(b['comm'])
             if not b['avg_in_op']:
@@ -121,7 +155,7 @@ class GradBuckets:
         if self.world > 1:
             for b in self.buckets:
                 if b['handle'] is None:
-                    dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
+                    all_reduce_sum(b['flat'], self.group)
                     b['flat'].div_(self.world)
         self._launched = []
 
@@ -141,7 +175,12 @@ def broadcast_parameters(module, src=0, group=None):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t, src=src, group=group)
+            if _host_side(group, t):
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=group)
     from . import functions
     functions.clear_weight_cache()          # the staged bf16 W / W^T copies of the old values are stale
 
@@ -152,14 +191,20 @@ def shard_clips(global_batch, rank, world):
 
 
 
-def init_process_group(device, rank=0, world=1, attempts=8):
+def init_process_group(device, rank=0, world=1, attempts=8, backend=None):
     """torch.distributed (RCCL) process group for one rank per GPU on a single node.  With more than one rank the launcher's
-    MASTER_ADDR / MASTER_PORT are used as they are.  A ONE-rank group (VTX_FORCE_DP=1: the DP code path on one GPU) needs no
+    MASTER_ADDR / MASTER_PORT are used as they are.  ``backend`` (default: $VTX_DP_BACKEND, else "nccl" = RCCL): "gloo" runs
+    the same data-parallel stack with the buckets staged through pinned host memory -- RCCL refuses two ranks on one device,
+    gloo does not, which is how the N > 1 path is tested on a one-GPU box (tests/test_gpu_dp.py).  A ONE-rank group (VTX_FORCE_DP=1: the DP code path on one GPU) needs no
     agreement with anybody about the port: it takes a free one itself and, because "free when probed" is not "free when the
     store binds it" (RCCL bootstrap sockets of an earlier group, another process), retries with another port on EADDRINUSE."""
-    import os
     import socket
+    backend = backend or os.environ.get('VTX_DP_BACKEND', 'nccl')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if backend != 'nccl':
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        return
     if world > 1:
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
