@@ -65,7 +65,9 @@ const char* vtx_last_error_string(void);
  * "gemm_tn" = auto|pp256|ring|dma2, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "attn_hw_fwd", "attn_hw_bwd" = n
  * (short-sequence attention: n heads of a row tile per workgroup, 0 = one head and four row tiles), "pp_grid", "pp_cg",
  * "pp_epi" = integers ("pp_epi": 1 = per-pass epilogue of the persistent GEMM; 2 / 3 = timing diagnostics that skip
- * its stores / its LDS staging and produce WRONG output), "pp_cont" = 0|1 (continuous flow of the persistent GEMM: the
+ * its stores / its LDS staging and produce WRONG output; 4 = the general passes instead of the lean ones of the
+ * continuous-flow kernels, 5 = lean passes (the default, same as 0), 6 = lean passes with the first four of every tile rolled
+ * into its last K tile -- 4 / 5 / 6 give identical results), "pp_cont" = 0|1 (continuous flow of the persistent GEMM: the
  * next tile's first K tiles are requested inside the current main loop; 1 by default, 0 = per-tile prologue; identical
  * results), "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown
  * name or value. */

@@ -423,7 +423,7 @@ def test_gemm_nt_pp_continuous_flow(N, K, vtx_opts):
         assert torch.equal(C, first)
 
 
-@pytest.mark.parametrize('K', [192, 768])
+@pytest.mark.parametrize('K', [192, 256, 768])
 def test_gemm_nt_pp_lean_passes(K, vtx_opts):
     """Lean epilogue passes of the continuous-flow kernels (scalar store base + 32-bit lane offset, software-pipelined LDS
     staging, row scales through ds_bpermute) against the general passes of the same kernels (pp_epi=4): bit-identical for
@@ -453,7 +453,7 @@ def test_gemm_nt_pp_lean_passes(K, vtx_opts):
 
     def run(**kw):
         outs = []
-        for epi in ('0', '4'):
+        for epi in ('0', '4', '6'):                 # lean passes, general passes, lean passes with the first four rolled into the last K tile
             vtx_opts('pp_epi', epi)
             C = torch.zeros(phys + 5 * G, N, dtype=dtype, device=DEV)
             C2 = torch.zeros(M, N, dtype=dtype, device=DEV)
@@ -462,7 +462,8 @@ def test_gemm_nt_pp_lean_passes(K, vtx_opts):
             else:
                 ops.gemm_nt(Xd, Wd, C, M, N, K, **kw)
             outs.append((C, C2))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), f'lean passes differ: {sorted(kw)} K={K}'
+        for o in outs[1:]:
+            assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), f'lean passes differ: {sorted(kw)} K={K}'
         return outs[0][0].float().cpu(), outs[0][1].float().cpu()
 
     for grid in ('256', '8'):

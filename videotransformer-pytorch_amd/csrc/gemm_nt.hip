@@ -148,6 +148,12 @@ __device__ inline void st16_nt_s(const char* sbase, unsigned voff, u32x4 v) {
   typedef __attribute__((address_space(1))) u32x4 g_u32x4;       // (the empty asm hides the pointer's origin: name the address space,
   __builtin_nontemporal_store(v, (g_u32x4*)(sbase + voff));      //  or the store becomes a FLAT one, which also counts on lgkmcnt)
 }
+// the same store for a base that was laundered already (under a lane predicate the asm would define a scalar register in
+// divergent control flow: "illegal VGPR to SGPR copy")
+__device__ inline void st16_nt_b(const char* sbase, unsigned voff, u32x4 v) {
+  typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+  __builtin_nontemporal_store(v, (g_u32x4*)(sbase + voff));
+}
 __device__ inline u32x4 pack8(const float (&v)[8]) {          // eight floats -> eight bf16 (v_cvt_pk_bf16_f32, round to nearest even)
   union { bf16x8 b; u32x4 u; } o;
 #pragma unroll
@@ -401,7 +407,7 @@ __device__ inline void lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory
 // under-wait on the DMA, because loads retire in order among themselves.)
 // PRE: what the epilogue reads per element: 0 nothing, 1 the residual, 2 the GELU' input x, 3 a plain multiplier
 enum { PRE_NONE = 0, PRE_RES = 1, PRE_DGELU = 2, PRE_MUL = 3 };
-template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT>
+template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT, bool ROLL = false>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     int M, int N, int K, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
     const bf16raw* __restrict__ B, long ldb, int tiles_n, int tiles_total, int CG, int* __restrict__ tile_ctr,
@@ -558,12 +564,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #define PP_READ_B(buf_, kind_, fb_)                                                                    \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
       fb_[ks] = *reinterpret_cast<const bf16x8*>(lds + (buf_) * PP_BUF + (kind_) * PP_REGION + b_grp + fr[ks]);
-#define PP_MMA(i0_, j_, fb_, ISSUE_)                                                                   \
+// HW_: inside the fence right behind the section's request (waits of a rolling pass); HB_: behind the fence, in the same
+// scheduling region as the section's remaining six MFMAs -- the compiler mixes it into their shadow
+#define PP_MMA(i0_, j_, fb_, ISSUE_) PP_MMA_H(i0_, j_, fb_, ISSUE_, , )
+#define PP_MMA_H(i0_, j_, fb_, ISSUE_, HW_, HB_)                                                       \
   __builtin_amdgcn_s_setprio(1);                                                                       \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
         acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
-    if (ks == 0) { __builtin_amdgcn_sched_barrier(0); ISSUE_; __builtin_amdgcn_sched_barrier(0); }     \
+    if (ks == 0) { __builtin_amdgcn_sched_barrier(0); ISSUE_; HW_ __builtin_amdgcn_sched_barrier(0); HB_ }     \
   }                                                                                                    \
   __builtin_amdgcn_s_setprio(0);
 #define PP_BAR() __builtin_amdgcn_s_barrier()
@@ -582,7 +591,12 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   // result stores of this wave's previous epilogue, so its steady-state count is raised by NST (relaxed first K tiles of a
   // tile, see `relax` in the continuous flow below)
 #define PP_KTILE(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_) PP_KTILE_X(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, false, false, false)
-#define PP_KTILE_X(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, X1_, X2_, X4_)                        \
+#define PP_KTILE_X(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, X1_, X2_, X4_) \
+    PP_KTILE_XH(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, X1_, X2_, X4_, false, false, , , , )
+// X1R_ (with X1_): the previous tile's epilogue ROLLED -- the NSR stores of its first two passes went out inside its last K
+// tile, ahead of the request this wait names; R4_: stores this section's predecessors issued behind the request P4's wait
+// names (a rolling last K tile: the two stores of F(0), run-time flag); M3W_ / M3B_ / M4W_ / M4B_: hooks of the MFMA sections of P3 / P4 (see PP_MMA_H)
+#define PP_KTILE_XH(E1_, E2_, W1_, W2_, W4_, ISS_, H1_, H2_, H3_, H4_, X1_, X2_, X4_, X1R_, R4_, M3W_, M3B_, M4W_, M4B_) \
     {                                                                                                  \
       const int buf = (kt & 1) ^ par;                                                                  \
       const bool e1 = (E1_), e2 = (E2_);           /* K tile kt+1 / kt+2 exists in this tile */        \
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       /* P1: reads A0, B0; P2 will read B1(kt) */                                                      \
       PP_READ_A(buf, 0);                                                                               \
       PP_READ_B(buf, 1, fb0);                                                                          \
-      if (w1) { if (X1_) wait_vmcnt<8 + NST>(); else wait_vmcnt<8>(); } else wait_vmcnt<2>();          \
+      if (w1) { if (X1_) { if (X1R_) wait_vmcnt<8 + NST - NSR>(); else wait_vmcnt<8 + NST>(); } else wait_vmcnt<8>(); } else wait_vmcnt<2>(); \
       H1_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
@@ -609,13 +623,13 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       H3_                                                                                              \
       lgkm0();                                                                                         \
       PP_BAR();                                                                                        \
-      PP_MMA(2, 1, fb1, ISS_(1, kt + 2, e2));                                                          \
+      PP_MMA_H(2, 1, fb1, ISS_(1, kt + 2, e2), M3W_, M3B_);                                            \
       PP_BAR();                                                                                        \
       /* P4: no reads; P1 of the next K tile will read A0(kt+1), B0(kt+1) */                           \
-      if (W4_) { if (w2) { if (X4_) wait_vmcnt<8 + NST>(); else wait_vmcnt<8>(); } else if (w1) wait_vmcnt<4>(); } \
+      if (W4_) { if (w2) { if (X4_) wait_vmcnt<8 + NST>(); else if (R4_) wait_vmcnt<10>(); else wait_vmcnt<8>(); } else if (w1) wait_vmcnt<4>(); } \
       H4_                                                                                              \
       PP_BAR();                                                                                        \
-      PP_MMA(2, 0, fb0, ISS_(2, kt + 2, e2));                                                          \
+      PP_MMA_H(2, 0, fb0, ISS_(2, kt + 2, e2), M4W_, M4B_);                                            \
       PP_BAR();                                                                                        \
     }
 #define PP_ISS_COND(kind_, ktv_, ex_) if (ex_) issue(kind_, ktv_)          /* only K tiles of this tile */
@@ -639,7 +653,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   // result stores one wave issues per tile when none of its 16 (pass, half-row) groups is empty: one per group, two with a
   // second output (the activation kernels are only instantiated for the FFN: GELU + GELU', or GELU + pre-activation copy)
   constexpr int NST = HAS_ACT ? 32 : 16;
+  constexpr int NSR = NST / 4;                   // ... of them by its first two passes (the ones a rolling epilogue issues before P4's request of the last K tile)
   bool relax = false;                            // continuous operand flow only; set at the end of every epilogue
+  bool prev_rolled = false;                      // ... which rolled: the stores of its first two passes precede the last K tile's P4 request
   int t = next_tile();
   const int tend = xcount;
   if (t >= tend) { check_out(); return; }
@@ -660,6 +676,98 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 fa[2][4], fb0[4], fb1[4];
     const bool more_c = CF && t_next < tend;     // continuous flow: another tile follows this one
+    // ---- epilogue state of this tile.  epi_head() fills the store addressing (after the main loop -- or in front of its last K
+    // tile when the epilogue ROLLS: the first four passes of a lean tile, rows 0 .. 63 of the wave's block, which are final
+    // after P2 of the last K tile, then run inside P3 / P4 of that K tile, in the shadow of its last sixteen MFMAs)
+    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
+    const int tile_m0 = m0;                        // first row of the whole 256-row tile (wave-uniform)
+    TileMap cm;
+    unsigned ldcb = 0, lean_skipb = 0;
+    bool lean = false;
+    [[maybe_unused]] bool rolled = false;
+    int lean_lb = 0;
+    const char* lean_cb = nullptr;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t lean_rsrc;   // ROLL: base = lean_cb, bytes up to the end of C's last valid row
+    float bcol[2] = {0.f, 0.f};
+    auto epi_head = [&]() {
+      cm = make_tile_map(ep.cmap, tile_m0);
+      ldcb = (unsigned)ep.ldc * 2u;                // bytes per C row
+      const long skipb64 = (long)cm.skip * (long)ldcb;
+      lean = CONT && (dbg == 0 || dbg == 5 || dbg == 6) && em0 + 127 < ep.M && en0 + 63 < ep.N && (ep.split_row <= 0 || em0 + 127 < ep.split_row) &&
+             cm.fast && cm.skip >= 0 && skipb64 < (1L << 30) && ep.ldc < (1L << 22) && PRE != PRE_DGELU;
+      if constexpr (HAS_ACT) lean = lean && ep.act == 2 && ep.ldc2 < (1L << 22);
+      if constexpr (ROLL) lean = true;             // what the host checked (launch_pp); ragged tiles by store predicates
+      // first physical row of the wave's block, and the local row from which the map's skip applies (none if the whole
+      // block lies behind the boundary: the skip is in the base then)
+      lean_lb = em0 < cm.bound ? cm.bound - em0 : 0x7fffffff;
+      lean_cb = reinterpret_cast<const char*>(ep.C) + ((cm.base_q + em0 + (em0 >= cm.bound ? (long)cm.skip : 0L)) * ep.ldc + en0) * 2;
+      lean_skipb = (unsigned)skipb64;
+      if constexpr (ROLL) {
+        // C ends behind the physical row of logical row M - 1 (closed-form map: the host checked it)
+        const long last = (long)ep.cmap.base + (ep.M - 1) + (ep.cmap.grp > 0 ? (long)((unsigned)(ep.M - 1) / (unsigned)ep.cmap.grp) * ep.cmap.skip : 0L);
+        // (a wave whose 64 columns lie beyond N -- a ragged last column tile -- gets an empty range: it stores nothing)
+        const long left = en0 < ep.N ? (reinterpret_cast<const char*>(ep.C) + (last + 1) * ep.ldc * 2) - lean_cb : 0L;
+        lean_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(lean_cb), 0, (int)(left < 0 ? 0 : (left > 0x7fffffffL ? 0x7fffffffL : left)), 0x00020000);
+      }
+    };
+    // Lean passes of the plain epilogue (packed row-pair staging; see PAIRS below), as stages: W(p) stages a pass, R(p) reads it
+    // back, F(p) permutes and stores.  All LDS accesses are inline asm with a known instruction count; the LDS executes a
+    // wave's instructions in issue order, so the stages form a software pipeline on ONE staging buffer and ONE register set.
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    [[maybe_unused]] unsigned pl_wa0 = 0, pl_wa1 = 0, pl_rd = 0, pl_v0 = 0;
+    [[maybe_unused]] int pl_p2 = 0;
+    [[maybe_unused]] u32x4 pl_w0, pl_w1;
+    auto pl_setup = [&]() {                        // lane constants from an opaque lane id: never hoisted out of the tile loop
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const unsigned stg0 = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg));
+      pl_p2 = ln >> 3;
+      // staging words as in PP_EPI2B: lane (col, hi) writes row pairs 2 hi + {0, 1, 4, 5} at word 132 hi + {0, 64, 264, 328} + 32 ni + col
+      pl_wa0 = stg0 + (unsigned)(((ln >> 5) * 132 + (ln & 31)) * 4);
+      pl_wa1 = pl_wa0 + 264 * 4;
+      pl_rd = stg0 + (unsigned)((pl_p2 * 64 + 4 * ((pl_p2 >> 1) & 1) + 8 * (pl_p2 >> 2) + (ln & 7) * 8) * 4);
+      pl_v0 = (unsigned)(2 * pl_p2) * ldcb + (unsigned)(ln & 7) * 16u;
+    };
+#define PP_LWAIT(n_, ...) asm volatile("s_waitcnt lgkmcnt(%[cnt])" : __VA_ARGS__ : [cnt] "n"(n_) : "memory"); __builtin_amdgcn_sched_barrier(0)
+#define PP_PWAIT(n_) PP_LWAIT(n_, "+v"(pl_w0), "+v"(pl_w1))
+#define PP_PW(mi_, half_)                                                                               \
+    {                                                                                                   \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) { \
+        union { bf16x2 v; unsigned u; } x;     /* row pairs 2 hi + 4 kk (registers 4 kk, 4 kk + 1) and + 1 (4 kk + 2, + 3) */ \
+        union { bf16x2 v; unsigned u; } y;     /* (no comma outside parentheses in here: the stages are macro ARGUMENTS of the K tile) */ \
+        x.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk] + bcol[ni]);                               \
+        x.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 1] + bcol[ni]);                           \
+        y.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 2] + bcol[ni]);                           \
+        y.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 3] + bcol[ni]);                           \
+        if (ni == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"(kk ? pl_wa1 : pl_wa0), "v"(x.u), "v"(y.u) : "memory"); \
+        else asm volatile("ds_write2_b32 %0, %1, %2 offset0:32 offset1:96" :: "v"(kk ? pl_wa1 : pl_wa0), "v"(x.u), "v"(y.u) : "memory"); \
+      }                                                                                                 \
+    }
+#define PP_PR() asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(pl_w0), "=&v"(pl_w1) : "v"(pl_rd) : "memory")
+#define PP_PF(p_)                                                                                       \
+    {                                                                                                   \
+      const char* base = lean_cb + (long)(16 * (p_)) * ldcb;                                            \
+      if constexpr (!ROLL) asm volatile("" : "+s"(base));   /* a scalar base (see st16_nt_s) */         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                   \
+        const unsigned sel = u ? 0x07060302u : 0x05040100u;                                             \
+        u32x4 o;                                                                                        \
+        o[0] = __builtin_amdgcn_perm(pl_w0[1], pl_w0[0], sel);                                          \
+        o[1] = __builtin_amdgcn_perm(pl_w0[3], pl_w0[2], sel);                                          \
+        o[2] = __builtin_amdgcn_perm(pl_w1[1], pl_w1[0], sel);                                          \
+        o[3] = __builtin_amdgcn_perm(pl_w1[3], pl_w1[2], sel);                                          \
+        const unsigned voff = pl_v0 + (u ? ldcb : 0u) + ((2 * pl_p2 + u >= lean_lb - 16 * (p_)) ? lean_skipb : 0u); \
+        /* ROLL: every tile comes through here, also the ragged last row tile -- the descriptor ends behind the last valid */ \
+        /* row of C, the range check of the buffer store drops the lanes beyond it (no predicate, no divergent branch)     */ \
+        if constexpr (ROLL) __builtin_amdgcn_raw_buffer_store_b128(o, lean_rsrc, voff + (unsigned)(16 * (p_)) * ldcb, 0, 2); \
+        else st16_nt_b(base, voff, o);                                                                  \
+      }                                                                                                 \
+    }
+    // ROLL kernels (launch_pp: the plain flow whose C map, leading dimension and K the host has checked): EVERY tile takes the lean
+    // stages -- rows / columns beyond M x N are handled by store predicates -- and the first four passes of every tile that has a
+    // successor in this workgroup run inside its last K tile.  (One code path on purpose: with a rolling AND a non-rolling copy of
+    // the last K tile behind the same loop hipcc splits the accumulator tuples at the join and spills 160 - 220 registers.)
+    constexpr bool ROLLK = ROLL;
+    static_assert(!ROLL || (CF && VTX_PP_BF16_STAGE && PRE == PRE_NONE && !HAS_SC && !HAS_ACT), "rolling: the plain continuous flow only");
     // Waits are per region and counted: each names the region the NEXT phase reads and leaves every
     // younger request in flight (2 DMA instructions per region; issue order A0 B0 B1 A1 per K tile).
     stamp(0);
@@ -730,9 +838,34 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         // as a wait for the stores -- 0.5 us per tile for a plain epilogue, 4.7 us for the FFN's two GELU outputs
         // (profiles/round2_pp_timeline_flows.txt, segment 0-1).  From P2 of K tile 1 on the waited-for regions are younger than
         // the stores.  `relax` (wave-uniform): this wave's last epilogue issued exactly NST stores.
-        for (; kt < nk; ++kt) {
-          PP_KTILE_X(true, true, true, true, true, PP_ISS_ALWAYS, PP_CF_H1, PP_CF_H2;, PP_CF_H3, PP_CF_H4,
-                     relax && kt < 2, relax && kt == 0, relax && kt == 0)
+        for (; kt < nk - 1; ++kt) {
+          PP_KTILE_XH(true, true, true, true, true, PP_ISS_ALWAYS, PP_CF_H1, PP_CF_H2;, PP_CF_H3, PP_CF_H4,
+                      relax && kt < 2, relax && kt == 0, relax && kt == 0, prev_rolled && kt == 1, false, , , , )
+        }
+        // The last K tile (nk >= 4 in ROLL kernels: none of the hooks above fires in K tile nk - 1, and the hand-over word in wave
+        // 0's staging slice -- written in K tile 1, read in K tile 2 -- is dead).  Rows 0 .. 63 of the wave's block are final after P2:
+        //   P3 load section   W(0) R(0)                  (behind the A1 fragment reads; the section's own lgkmcnt(0) covers R(0))
+        //   P3 MFMA section   F(0) W(1) R(1)             (behind the section's request: its two stores are YOUNGER than that request;
+        //                                                 straight-line code in the scheduling region of the last six MFMAs)
+        //   P4 load section   wait F(1) W(2) R(2)        (behind the section's counted wait, which gains the two stores of F(0) --
+        //                                                 when they were issued: a full block; a ragged one keeps the plain count)
+        //   P4 MFMA section   wait F(2) W(3) R(3)
+        // and the rest -- F(3), passes 4 .. 7 -- runs behind the loop as before.
+        if constexpr (ROLLK) {
+          epi_head();
+          rolled = true;
+          const bool full = em0 + 127 < ep.M && en0 + 63 < ep.N && trace == nullptr;
+          if (ep.bias) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                                    : "=&v"(bcol[0]), "=&v"(bcol[1]) : "v"(bias_rd) : "memory");
+          pl_setup();
+          PP_KTILE_XH(true, true, true, true, true, PP_ISS_ALWAYS, , , PP_PW(0, 0) PP_PR();,
+                      PP_PWAIT(0); PP_PF(1) PP_PW(1, 0) PP_PR();,
+                      false, false, false, false, full,
+                      , PP_PF(0) PP_PW(0, 1) PP_PR();,
+                      PP_PWAIT(0);, PP_PF(2) PP_PW(1, 1) PP_PR();)
+        } else {
+          PP_KTILE_XH(true, true, true, true, true, PP_ISS_ALWAYS, PP_CF_H1, PP_CF_H2;, PP_CF_H3, PP_CF_H4,
+                      relax && kt < 2, relax && kt == 0, relax && kt == 0, prev_rolled && kt == 1, false, , , , )
         }
 #undef PP_CF_H1
 #undef PP_CF_H2
@@ -802,7 +935,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     }
     if (wr == 0) PP_BAR();                        // pairs with group 1's extra barrier: every wave is past its last LDS read
     stamp(2);
-    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
     if constexpr (!EPI2) {
       t = next_tile();
       const bool more = t < tend;
@@ -855,19 +987,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       const int er = em0 + (le >> 3);            // row of pass p, half-row u: er + 16 p + 8 u
       constexpr bool HAS_PRE = PRE != PRE_NONE, pre_res = PRE == PRE_RES;
       bf16raw* const pre_lds = lds + wave * (128 * 64);          // [128][64] bf16, row r at r * 64: le-linear per piece
-      const int tile_m0 = em0 - wr * 128;          // first row of the whole 256-row tile (wave-uniform)
-      const TileMap cm = make_tile_map(ep.cmap, tile_m0);
-      const unsigned ldcb = (unsigned)ep.ldc * 2u;                     // bytes per C row
-      const long skipb64 = (long)cm.skip * (long)ldcb;
-      bool lean = CONT && dbg == 0 && em0 + 127 < ep.M && en0 + 63 < ep.N && (ep.split_row <= 0 || em0 + 127 < ep.split_row) &&
-                  cm.fast && cm.skip >= 0 && skipb64 < (1L << 30) && ep.ldc < (1L << 22) && PRE != PRE_DGELU;
-      if constexpr (HAS_ACT) lean = lean && ep.act == 2 && ep.ldc2 < (1L << 22);
-      // first physical row of the wave's block, and the local row from which the map's skip applies (none if the whole
-      // block lies behind the boundary: the skip is in the base then)
-      const int lean_lb = em0 < cm.bound ? cm.bound - em0 : 0x7fffffff;
-      const char* const lean_cb = reinterpret_cast<const char*>(ep.C) +
-                                  ((cm.base_q + em0 + (em0 >= cm.bound ? (long)cm.skip : 0L)) * ep.ldc + en0) * 2;
-      const unsigned lean_skipb = (unsigned)skipb64;
+      if (!rolled) epi_head();                       // (a rolling epilogue did it in front of the last K tile)
       if constexpr (HAS_PRE && !PF) {
         const bf16raw* const pre_base = reinterpret_cast<const bf16raw*>(pre_res ? ep.R : ep.dgelu_in);
         const long pre_ld = pre_res ? ep.ldr : ep.ld_dgelu;
@@ -888,8 +1008,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       }
       // bias in the ACCUMULATOR layout (a le owns one column of each 32-column half: 2 registers instead of the 8 a
       // row-vector le needs, and 64 adds per tile instead of 128); same fp32 add, same result
-      float bcol[2] = {0.f, 0.f};
-      if (ep.bias) {
+      if (ep.bias && !rolled) {
         if constexpr (CF) {                        // landed in the staging slice during K tile 0 (see above)
           asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(bcol[0]), "=&v"(bcol[1]) : "v"(bias_rd) : "memory");
@@ -1068,57 +1187,27 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
       //     W(0) R(0) | W(1) wait F(0) R(1) | W(2) wait F(1) R(2) | ... | W(7) wait F(6) R(7) | wait F(7)
       // Same values in the same order as the general passes (bit-identical: tests/test_gpu_kernels.py::test_gemm_nt_pp_lean_passes).
       const unsigned stg_wr0 = (unsigned)(unsigned long)(lds_char*)(reinterpret_cast<char*>(stg)) ;
-#define PP_LWAIT(n_, ...) asm volatile("s_waitcnt lgkmcnt(%[cnt])" : __VA_ARGS__ : [cnt] "n"(n_) : "memory"); __builtin_amdgcn_sched_barrier(0)
       if (lean) {
         int ln = le;                               // opaque copy: the le constants below are recomputed per tile (a dozen vector
         asm volatile("" : "+v"(ln));                 // instructions) instead of living in registers through the main loop
         if constexpr (PAIRS) {
-          // staging words as in PP_EPI2B: le (col, hi) writes row pairs 2 hi + {0, 1, 4, 5} at word 132 hi + {0, 64, 264, 328} + 32 ni + col
-          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-          const int p2 = ln >> 3;
-          const unsigned wa0 = stg_wr0 + (unsigned)(((ln >> 5) * 132 + (ln & 31)) * 4), wa1 = wa0 + 264 * 4;
-          const unsigned pair_rd = stg_wr0 + (unsigned)((p2 * 64 + 4 * ((p2 >> 1) & 1) + 8 * (p2 >> 2) + (ln & 7) * 8) * 4);
-          const unsigned v0 = (unsigned)(2 * p2) * ldcb + (unsigned)(ln & 7) * 16u;
-          u32x4 w0, w1;
-#define PP_LW(mi_, half_)                                                                               \
-          {                                                                                             \
-            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) { \
-              union { bf16x2 v; unsigned u; } x, y;  /* row pairs 2 hi + 4 kk (registers 4 kk, 4 kk + 1) and + 1 (4 kk + 2, + 3) */ \
-              x.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk] + bcol[ni]);                         \
-              x.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 1] + bcol[ni]);                     \
-              y.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 2] + bcol[ni]);                     \
-              y.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 3] + bcol[ni]);                     \
-              if (ni == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"(kk ? wa1 : wa0), "v"(x.u), "v"(y.u) : "memory"); \
-              else asm volatile("ds_write2_b32 %0, %1, %2 offset0:32 offset1:96" :: "v"(kk ? wa1 : wa0), "v"(x.u), "v"(y.u) : "memory"); \
-            }                                                                                           \
+          // the stages are defined in front of the main loop (PP_PW / PP_PR / PP_PF): a rolling epilogue has run
+          // W(0) R(0) F(0) ... W(3) R(3) inside the last K tile and continues here with F(3)
+          if (rolled) {
+            PP_PWAIT(0); PP_PF(3)
+          } else {
+            pl_setup();
+            PP_PW(0, 0) PP_PR();
+            PP_PW(0, 1) PP_PWAIT(4); PP_PF(0) PP_PR();
+            PP_PW(1, 0) PP_PWAIT(4); PP_PF(1) PP_PR();
+            PP_PW(1, 1) PP_PWAIT(4); PP_PF(2) PP_PR();
+            PP_PWAIT(0); PP_PF(3)
           }
-#define PP_LR() asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(w0), "=&v"(w1) : "v"(pair_rd) : "memory")
-#define PP_LF(p_)                                                                                       \
-          {                                                                                             \
-            const char* const base = lean_cb + (long)(16 * (p_)) * ldcb;                                \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
-              const unsigned sel = u ? 0x07060302u : 0x05040100u;                                       \
-              u32x4 o;                                                                                  \
-              o[0] = __builtin_amdgcn_perm(w0[1], w0[0], sel);                                          \
-              o[1] = __builtin_amdgcn_perm(w0[3], w0[2], sel);                                          \
-              o[2] = __builtin_amdgcn_perm(w1[1], w1[0], sel);                                          \
-              o[3] = __builtin_amdgcn_perm(w1[3], w1[2], sel);                                          \
-              const unsigned voff = v0 + (u ? ldcb : 0u) + ((2 * p2 + u >= lean_lb - 16 * (p_)) ? lean_skipb : 0u); \
-              st16_nt_s(base, voff, o);                                                                 \
-            }                                                                                           \
-          }
-          PP_LW(0, 0) PP_LR();
-          PP_LW(0, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(0) PP_LR();
-          PP_LW(1, 0) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(1) PP_LR();
-          PP_LW(1, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(2) PP_LR();
-          PP_LW(2, 0) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(3) PP_LR();
-          PP_LW(2, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(4) PP_LR();
-          PP_LW(3, 0) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(5) PP_LR();
-          PP_LW(3, 1) PP_LWAIT(4, "+v"(w0), "+v"(w1)); PP_LF(6) PP_LR();
-          PP_LWAIT(0, "+v"(w0), "+v"(w1)); PP_LF(7)
-#undef PP_LW
-#undef PP_LR
-#undef PP_LF
+          PP_PW(2, 0) PP_PR();
+          PP_PW(2, 1) PP_PWAIT(4); PP_PF(4) PP_PR();
+          PP_PW(3, 0) PP_PWAIT(4); PP_PF(5) PP_PR();
+          PP_PW(3, 1) PP_PWAIT(4); PP_PF(6) PP_PR();
+          PP_PWAIT(0); PP_PF(7)
         } else {
           // fp32 staging as in PP_EPI2: le (col, hi) writes rows 4 hi + {0, 1, 2, 3, 8, 9, 10, 11} at word 256 hi + {0, 64, 128, 192, 512, ...} + 32 ni + col
           const unsigned wa0 = stg_wr0 + (unsigned)(((ln >> 5) * 256 + (ln & 31)) * 4), wa1 = wa0 + 512 * 4;
@@ -1261,7 +1350,6 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
         PP_EPI2(0, 0, 0) PP_EPI2(1, 0, 1) PP_EPI2(2, 1, 0) PP_EPI2(3, 1, 1)
         PP_EPI2(4, 2, 0) PP_EPI2(5, 2, 1) PP_EPI2(6, 3, 0) PP_EPI2(7, 3, 1)
       }
-#undef PP_LWAIT
 #undef PP_EPI2
       stamp(6);
       if constexpr (HAS_PRE && !PF) {
@@ -1278,7 +1366,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           // out (rows em0 + 8 g + [0, 8), g = 0 .. 15; a store with an empty execution mask is not issued); the timeline and
           // the store-free diagnostic mode add or drop vector memory operations
           const bool second = !HAS_ACT || ep.act == 2 || ep.C2 != nullptr;
-          relax = em0 + 120 < ep.M && en0 < ep.N && second && trace == nullptr && (dbg == 0 || dbg == 4) && nk >= 3;
+          relax = em0 + 120 < ep.M && en0 < ep.N && second && trace == nullptr && (dbg == 0 || dbg == 4 || dbg == 5 || dbg == 6) && nk >= 3;
+          prev_rolled = rolled;
         }
         m0 = m0s; n0 = n0s;
         par ^= nk & 1;
@@ -1288,6 +1377,11 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
   }
   check_out();
 #undef PP_KTILE
+#undef PP_LWAIT
+#undef PP_PWAIT
+#undef PP_PW
+#undef PP_PR
+#undef PP_PF
 #undef PP_ISS_COND
 #undef PP_ISS_ALWAYS
 #undef PP_ISS_PRE
@@ -1297,11 +1391,11 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #undef PP_BAR
 }
 
-template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT>
+template <bool EPI2, int PRE, bool HAS_SC, bool HAS_ACT, bool CONT, bool ROLL = false>
 static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st, const Options& cfg) {
   static std::atomic<unsigned long long> attr_set{0};
   if (first_launch_on_device(attr_set)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT, ROLL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         PP_LDS_BYTES);
   }
   const int tiles_m = cdiv(d->M, PP_BM), tiles_n = cdiv(d->N, PP_BN);
@@ -1311,7 +1405,7 @@ static int launch_pp_t(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t 
   if (!cfg.pp_cg && cg < 3) cg = 3;
   if (!cfg.pp_cg && cg > 6) cg = 6;
   if (cg < 1) cg = 1;
-  hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
+  hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI2, PRE, HAS_SC, HAS_ACT, CONT, ROLL>), dim3(cfg.pp_grid), dim3(PP_THREADS), PP_LDS_BYTES, st, d->M, d->N, d->K,
                      (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, tiles_n, tiles_m * tiles_n, cg,
                      (int*)d->workspace, EPI2 ? reinterpret_cast<long long*>(cfg.pp_trace) : nullptr, cfg.pp_epi, ep);
   return check_launch("gemm_nt_pp");
@@ -1344,6 +1438,16 @@ static int launch_pp(const vtx_gemm_desc* d, const EpiParams& ep, hipStream_t st
     return cont ? launch_pp_t<true, PRE_RES, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_RES, false, false, false>(d, ep, st, cfg);
   }
   if (sc) return cont ? launch_pp_t<true, PRE_NONE, true, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, true, false, false>(d, ep, st, cfg);
+  // rolling epilogue (pp_epi = 6; NOT the default: measured on the three plain shapes of a layer, interleaved same-process A/B,
+  // profiles/round4_nt_roll_ab.txt: +0.3 / +0.6 / +1.0 % over the lean passes behind the loop, GRBM_GUI_ACTIVE unchanged -- the
+  // passes are bound by instruction issue, and the issue slots they take inside the last K tile stretch its sections by what
+  // the shorter epilogue saves): every tile takes the lean stages, so what they assume is checked here for the whole launch -- a closed-form C
+  // map with at most one group boundary per tile and a byte skip below 2^30, no split rows, four K tiles or more, whole 64-column
+  // blocks (rows beyond M are dropped by the range check of the stores' buffer descriptor)
+  const bool roll = cont && cfg.pp_epi == 6 && d->K / PP_BK >= 4 && d->N % 64 == 0 && d->split_row <= 0 && closed_form(d->cmap) &&
+                    (d->cmap.grp <= 0 || d->cmap.grp >= 256) && d->cmap.skip >= 0 && d->ldc < (1L << 22) &&
+                    (long)(d->cmap.grp > 0 ? d->cmap.skip : 0) * d->ldc * 2 < (1L << 30);
+  if (roll) return launch_pp_t<true, PRE_NONE, false, false, true, true>(d, ep, st, cfg);
   return cont ? launch_pp_t<true, PRE_NONE, false, false, true>(d, ep, st, cfg) : launch_pp_t<true, PRE_NONE, false, false, false>(d, ep, st, cfg);
 }
 
