@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 FLOPS_FWD_BWD_PER_CLIP = {8: 1.175e12, 16: 2.352e12, 2: 0.2937e12}
 PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0         # TB/s (spec; ~6.3 TB/s is what a streaming copy reaches)
-PMC_ROUNDS = ('round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
+PMC_ROUNDS = ('round4_', 'round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
 
 
 def parse():
@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true', help='skip the instrumented per-kernel-class pass')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help="skip the 5-step mini-runs of north_star's other shapes after the timed region (other_configs in the JSON line)")
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--no-direct-grads', action='store_true',
                     help='parameter gradients through autograd accumulation instead of straight into the buckets')
@@ -247,6 +249,97 @@ def gemm_shape_table(per_shape, peak_tf):
     return rows
 
 
+def other_configs(dev, model8, head8, budget_s=20.0):
+    """north_star's other shapes on the driver-witnessed line: 5-step mini-runs AFTER the timed region (never part of `value`),
+    same step structure as the headline (bf16, buckets with direct gradients, fused optimizer, synthetic clips resident in HBM),
+    under a hard wall-clock budget -- a configuration that would start beyond it is reported as skipped."""
+    import vtx
+    from vtx import dp, optim, functions as F_
+    import transformer as T
+    import video_transformer as V
+    t_begin = time.perf_counter()
+    out = []
+
+    def run(workload, build, batch, frames, flops_per_clip, extra=None, steps=5, warmup=2):
+        if time.perf_counter() - t_begin > budget_s:
+            out.append({'workload': workload, 'skipped': 'time budget of %.0f s for other_configs used up' % budget_s})
+            return
+        vtx.set_precision('bf16')
+        torch.manual_seed(0)
+        stepfn, cleanup = build(batch, frames)
+        try:
+            for _ in range(warmup):
+                stepfn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                stepfn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            row = {'workload': workload, 'clips_per_gpu': batch, 'clips_per_s': round(batch / dt, 2), 'ms_per_step': round(dt * 1e3, 3),
+                   'steps': steps, 'mfma_frac_nominal': round(batch / dt * flops_per_clip / 1e12 / PEAK_BF16, 4) if flops_per_clip else None}
+            row.update(extra or {})
+            out.append(row)
+        finally:
+            cleanup()
+            torch.cuda.empty_cache()
+
+    def classifier(model, head):
+        def build(batch, frames):
+            params = list(model.parameters()) + list(head.parameters())
+            buckets = dp.GradBuckets(params, direct=True)
+            opt = optim.FusedSGD(buckets, lr=1e-4, momentum=0.9, nesterov=True)
+            x = torch.randn(batch, frames, 3, 224, 224, device=dev)
+            y = torch.randint(0, 400, (batch,), device=dev)
+
+            def stepfn():
+                buckets.zero()
+                F_.SoftmaxXentFn.apply(head(model(x)), y).backward()
+                buckets.finish()
+                opt.step()
+            return stepfn, buckets.remove
+        return build
+
+    def fresh(ctor):
+        m = ctor().to(dev).train()
+        return m, T.ClassificationHead(400, m.embed_dims).to(dev).train()
+
+    # the headline model at the batch the reference trains at (8 clips per GPU, demo log) and at 32 clips
+    for b in (8, 32):
+        run('TimeSformer-B divided_space_time, 8x3x224x224, bf16, fwd+CE+bwd+SGD (headline model, %d clips per GPU)' % b,
+            classifier(model8, head8), b, 8, FLOPS_FWD_BWD_PER_CLIP[8])
+    run('TimeSformer-B divided_space_time, 16x3x224x224, bf16, fwd+CE+bwd+SGD (north_star second shape)',
+        classifier(*fresh(lambda: V.TimeSformer(num_frames=16))), 48, 16, FLOPS_FWD_BWD_PER_CLIP[16])
+    run('ViViT-B fact_encoder, Conv3d tubelet 2, 16x3x224x224, bf16, fwd+CE+bwd+SGD (BASELINE configs[2])',
+        classifier(*fresh(lambda: V.ViViT(num_frames=16))), 32, 16, 0.850e12)
+
+    def maskfeat(batch, frames):
+        from vtx import ops
+        m = V.MaskFeat(pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]], feature_dim=216).to(dev).train()
+        opt = optim.FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.05, clip_grad=0.02)
+        x = torch.randn(batch, 16, 3, 224, 224, device=dev)
+        fr = torch.randint(0, 256, (batch * 3, 224, 224, 3), dtype=torch.uint8, device=dev)
+        mask = torch.zeros(batch, 8, 14, 14, dtype=torch.int32)
+        mask[:, 2:4, 3:9, 2:10] = 1
+        mask[:, 6, 5:12, 5:12] = 1
+        mask = mask.to(dev)
+        markers = [[[2, 2], [6, 1]]] * batch
+
+        def stepfn():
+            hog = ops.hog_fwd(fr)                       # HOG targets on the device, inside the step
+            target = torch.zeros(batch, 16, 14, 14, 108, dtype=torch.float64, device=dev)
+            target[:, 6] = hog[0::3]
+            target[:, 13] = hog[1::3]
+            m.zero_grad(set_to_none=True)
+            _, loss = m(x, target, mask, markers)
+            loss.backward()
+            opt.step()
+        return stepfn, (lambda: None)
+    run('MaskFeat: MViT-B + HOG-target masked MSE, 16x3x224x224, bf16, fwd+bwd+AdamW, HOG targets computed in the step (BASELINE configs[3], one GPU)',
+        maskfeat, 32, 16, 3 * 70.6e9, extra={'parity': 'unpinned (the MViT oracle restates pytorchvideo 0.1.3, which is on no disk: DESIGN.md 5)'})
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -355,6 +448,15 @@ def main():
         classes = ops.profile_stop()
         classes['_step_ms'] = step_ms
         classes['_steps'] = nb
+    others = None
+    if world == 1 and not force_dp and not args.no_other_configs and args.precision == 'bf16' and args.frames == 8:
+        buckets.remove()                                # the mini-runs build their own buckets over the same parameters
+        del x
+        torch.cuda.empty_cache()
+        try:
+            others = other_configs(dev, model, head)
+        except Exception as e:                          # the headline line must survive anything that happens here
+            others = [{'error': repr(e)[:300]}]
     if world > 1:
         dist.barrier()
 
@@ -423,6 +525,8 @@ def main():
                                 'frac': round(a / PEAK_HBM, 4), 'avg_launch_us': round(cms / cn * 1e3, 1),
                                 'algorithmic_mb_per_launch': round(cby / cn / 1e6, 2), 'ms_per_step': per_step})
             out['roofline_hbm'] = hbm
+        if others is not None:
+            out['other_configs'] = others
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_subprocess(args.frames)
     else:

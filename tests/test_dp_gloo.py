@@ -44,7 +44,11 @@ def _worker(rank, world, port, ret):
 
 def test_bucketed_allreduce_world2():
     world = 2
-    port = 29500 + (os.getpid() % 1000)
+    import socket
+    sock = socket.socket()                              # a free port picked by the kernel (a fixed 295xx one collides with a
+    sock.bind(('127.0.0.1', 0))                         # leftover store of an earlier run: EADDRINUSE)
+    port = sock.getsockname()[1]
+    sock.close()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)

@@ -312,6 +312,70 @@ def test_direct_parameter_gradients_match_autograd_accumulation():
             functions.set_direct_grads(False)
 
 
+def _ffn_drop_pattern(seed, B, P, T, layers, rate=0.1):
+    """The FFN DropPath masks a training forward draws after torch.manual_seed(seed): per layer with p > 0 the reference draws
+    (B*P) temporal, (B*T) spatial and B FFN values from the CPU generator, in that order (transformer.py:34-42, 268-275, 371-377, 543)."""
+    torch.manual_seed(seed)
+    out = []
+    for p in np.linspace(0, rate, layers):
+        if p == 0:
+            out.append([False] * B)
+            continue
+        torch.rand(B * P, 1, 1)
+        torch.rand(B * T, 1, 1)
+        u = torch.rand(B, 1, 1).reshape(B)
+        out.append([bool(np.floor(np.float32(1 - p) + np.float32(v)) == 0) for v in u.tolist()])
+    return out
+
+
+@pytest.mark.parametrize('prec,tol,gtol', PRECS)
+def test_bench_stack_vs_oracle_with_partial_ffn_drop(prec, tol, gtol):
+    """The stack bench.py times -- GradBuckets(direct=True) (kernels accumulate into the bucket views), DropPath-aware
+    compaction of the FFN with SOME BUT NOT ALL clips of a layer dropped (table row maps: >= 256 rows per clip), the merged
+    attn.proj o temporal_fc projection -- against the reference restatement (oracle.timesformer_forward with the same CPU
+    draws) at 8 clips: outputs and every parameter gradient.  The committed goldens are B <= 3 and never drop part of a batch."""
+    import vtx
+    import video_transformer as V
+    from vtx import dp, functions
+    B, T, L = 8, 16, 4
+    cfg = dict(img_size=64, patch_size=16, embed_dims=128, num_heads=2, num_transformer_layers=L)
+    P = (64 // 16) ** 2
+    assert 1 + P * T >= 256, 'the compact path needs >= 256 rows per clip'
+    seed = next(s for s in range(200) if any(0 < sum(l) < B for l in _ffn_drop_pattern(s, B, P, T, L)))
+    pattern = _ffn_drop_pattern(seed, B, P, T, L)
+    report(f'bench-stack test: seed {seed}, dropped clips per layer {[sum(l) for l in pattern]}')
+    vtx.set_precision(prec)
+    assert functions._compact and functions._merge_tfc, 'defaults: compaction and merged projection on'
+    m, sd = _build(V.TimeSformer, 5, num_frames=T, **cfg)
+    x = synth.synth_clip(B, T, 3, 64, 64, seed=4)
+    w = synth_tensor('loss_w', (128,), 0) * 10.0
+    buckets = dp.GradBuckets(list(m.parameters()), bucket_bytes=256 << 10, direct=True)
+    try:
+        buckets.zero()
+        m.train()
+        torch.manual_seed(seed)
+        y = m(x.to(DEV))
+        (y * w.to(DEV)).sum().backward()
+        buckets.finish()
+        torch.cuda.synchronize()
+        assert all(b['pending'] == 0 for b in buckets.buckets)
+        grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    finally:
+        buckets.remove()
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.manual_seed(seed)
+    yo = O.timesformer_forward(ps, x, T, heads=2, layers=L, training=True)
+    (yo * w).sum().backward()
+    check(f'bench stack {prec} out', y.detach().cpu(), yo.detach(), tol)
+    worst = 0.0
+    for k, g in grads.items():
+        ref = ps[k].grad
+        e = (g.double() - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-30)
+        worst = max(worst, e)
+        assert e <= gtol, f'{prec} {k}: {e:.3e} > {gtol}'
+    report(f'bench stack {prec}: worst parameter gradient l2-rel {worst:.3e}')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,rows_per,D,Hd', [(5, 37, 128, 256), (6, 1569, 768, 3072)])
 def test_ffn_skips_dropped_clips(dtype, B, rows_per, D, Hd):

@@ -61,6 +61,35 @@ def test_fused_step_matches_torch(kind, clip):
             check(f'{kind} clip={clip} step {step} param {i}', pg.detach().cpu(), pr.detach(), 2e-6)
 
 
+def test_unused_parameters_take_no_update():
+    """With gradient buckets every .grad is a zero-filled view, never None: a parameter outside the step's graph is named
+    through set_skipped() and then behaves like torch's `grad is None` -- no weight decay, no moment update."""
+    from vtx import optim
+    init = _params(3)
+    p_ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    p_gpu = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    o_ref = torch.optim.AdamW(p_ref, lr=0.01, weight_decay=0.1)
+    o_gpu = optim.FusedAdamW(p_gpu, lr=0.01, weight_decay=0.1)
+    unused = {1, 4}
+    for step in range(3):
+        grads = _params(20 + step)
+        for i, (pr, pg, g) in enumerate(zip(p_ref, p_gpu, grads)):
+            pr.grad = None if i in unused else g.clone().double()
+            pg.grad = torch.zeros_like(pg) if i in unused else g.clone().to(DEV)     # what a bucket view looks like
+        o_gpu.set_skipped([p_gpu[i] for i in unused])
+        o_ref.step()
+        o_gpu.step()
+        if step == 1:
+            unused = {4}                                # parameter 1 joins the graph later: its first update is step 1 of ITS history
+            # (torch keeps a per-parameter step count; the fused class keeps one for all -- compare the untouched one only)
+    check('unused parameter stays put', p_gpu[4].detach().cpu(), init[4], 0.0 + 1e-12)
+    for i in (0, 2, 3, 5, 6, 7):
+        check(f'used parameter {i}', p_gpu[i].detach().cpu(), p_ref[i].detach(), 2e-6)
+    sd = o_gpu.state_dict()
+    assert all('step' not in st for st in o_gpu.state.values()), "state_dict() must not leave a 'step' key in the live state"
+    assert all('step' in st for st in sd['state'].values())
+
+
 @pytest.mark.parametrize('kind', ['sgd', 'adamw'])
 def test_checkpoint_resume_matches_torch(kind):
     """Save after two updates, load into FRESH optimizers (the fused one and torch's), continue: the AdamW bias correction

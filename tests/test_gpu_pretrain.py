@@ -48,7 +48,7 @@ def test_single_run_supervised_two_epochs_then_resume(tmp_path, monkeypatch):
     assert abs(tr.args.lr - 0.01) < 1e-12
     ckpt = os.path.join(str(tmp_path), 'results', MP.experiment_tag(tr.args), 'ckpt', 'last_checkpoint.pth')
     state = torch.load(ckpt, map_location='cpu')
-    assert state['epoch'] == 1 and state['global_step'] == 4 and len(state['state_dict']) > 240
+    assert state['epoch'] == 2 and state['global_step'] == 4 and len(state['state_dict']) > 240    # Lightning: current_epoch + 1
     moved = tr.model.model.transformer_layers.layers[3].ffns[0].layers[1].weight.detach().clone()
     # resume: one more epoch from the checkpoint (the tag is computed from the scaled lr, so pass the path)
     monkeypatch.setenv('MASTER_PORT', _port())

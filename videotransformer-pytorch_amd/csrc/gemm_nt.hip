@@ -154,6 +154,8 @@ __device__ inline void st16_nt_b(const char* sbase, unsigned voff, u32x4 v) {
   typedef __attribute__((address_space(1))) u32x4 g_u32x4;
   __builtin_nontemporal_store(v, (g_u32x4*)(sbase + voff));
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ inline f32x2 mk2(float a, float b) { f32x2 r; r[0] = a; r[1] = b; return r; }
 __device__ inline u32x4 pack8(const float (&v)[8]) {          // eight floats -> eight bf16 (v_cvt_pk_bf16_f32, round to nearest even)
   union { bf16x8 b; u32x4 u; } o;
 #pragma unroll
@@ -730,15 +732,19 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
     };
 #define PP_LWAIT(n_, ...) asm volatile("s_waitcnt lgkmcnt(%[cnt])" : __VA_ARGS__ : [cnt] "n"(n_) : "memory"); __builtin_amdgcn_sched_barrier(0)
 #define PP_PWAIT(n_) PP_LWAIT(n_, "+v"(pl_w0), "+v"(pl_w1))
-#define PP_PW(mi_, half_)                                                                               \
+// (the bias add of a register pair is ONE v_pk_add_f32 -- same IEEE add per element --, and a launch without a bias skips it:
+// acc + 0.0f is acc bit for bit, an accumulator that started from +0 never holds -0)
+#define PP_PW(mi_, half_) if (ep.bias) { PP_PW_(mi_, half_, true) } else { PP_PW_(mi_, half_, false) }
+#define PP_PW_(mi_, half_, B_)                                                                          \
     {                                                                                                   \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) { \
+        f32x2 lo = mk2(acc[mi_][ni][8 * (half_) + 4 * kk], acc[mi_][ni][8 * (half_) + 4 * kk + 1]);     \
+        f32x2 hi = mk2(acc[mi_][ni][8 * (half_) + 4 * kk + 2], acc[mi_][ni][8 * (half_) + 4 * kk + 3]); \
+        if (B_) { const f32x2 b2 = mk2(bcol[ni], bcol[ni]); lo = lo + b2; hi = hi + b2; }               \
         union { bf16x2 v; unsigned u; } x;     /* row pairs 2 hi + 4 kk (registers 4 kk, 4 kk + 1) and + 1 (4 kk + 2, + 3) */ \
         union { bf16x2 v; unsigned u; } y;     /* (no comma outside parentheses in here: the stages are macro ARGUMENTS of the K tile) */ \
-        x.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk] + bcol[ni]);                               \
-        x.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 1] + bcol[ni]);                           \
-        y.v[0] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 2] + bcol[ni]);                           \
-        y.v[1] = (__bf16)(acc[mi_][ni][8 * (half_) + 4 * kk + 3] + bcol[ni]);                           \
+        x.v[0] = (__bf16)lo[0]; x.v[1] = (__bf16)lo[1];                                                 \
+        y.v[0] = (__bf16)hi[0]; y.v[1] = (__bf16)hi[1];                                                 \
         if (ni == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"(kk ? pl_wa1 : pl_wa0), "v"(x.u), "v"(y.u) : "memory"); \
         else asm volatile("ds_write2_b32 %0, %1, %2 offset0:32 offset1:96" :: "v"(kk ? pl_wa1 : pl_wa0), "v"(x.u), "v"(y.u) : "memory"); \
       }                                                                                                 \
@@ -1219,12 +1225,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           u32x4 pre[2];
           float scu[2] = {1.f, 1.f};                   // the pass's two row scales (rows le / 8 and + 8 of its 16)
           const unsigned bp_addr = (unsigned)(ln >> 3) * 4u;
-#define PP_LW(mi_, half_)                                                                               \
+#define PP_LW(mi_, half_) if (ep.bias) { PP_LW_(mi_, half_, true) } else { PP_LW_(mi_, half_, false) }
+#define PP_LW_(mi_, half_, B_)                                                                          \
           {                                                                                             \
             _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
             _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2) {                                          \
-              const float x = acc[mi_][ni][8 * (half_) + 4 * kk + 2 * r2] + bcol[ni];                   \
-              const float y = acc[mi_][ni][8 * (half_) + 4 * kk + 2 * r2 + 1] + bcol[ni];               \
+              f32x2 xy = mk2(acc[mi_][ni][8 * (half_) + 4 * kk + 2 * r2], acc[mi_][ni][8 * (half_) + 4 * kk + 2 * r2 + 1]); \
+              if (B_) { const f32x2 b2 = mk2(bcol[ni], bcol[ni]); xy = xy + b2; }                       \
+              const float x = xy[0];                                                                    \
+              const float y = xy[1];                                                                    \
               const unsigned wa = kk ? wa1 : wa0;                                                       \
               if (ni == 0 && r2 == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"(wa), "v"(x), "v"(y) : "memory"); \
               if (ni == 0 && r2 == 1) asm volatile("ds_write2_b32 %0, %1, %2 offset0:128 offset1:192" :: "v"(wa), "v"(x), "v"(y) : "memory"); \
@@ -1299,6 +1308,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
           PP_LW(3, 1) PP_LWAITF(8) PP_LF(6) PP_LR(7);
           PP_LWAITF(0) PP_LF(7)
 #undef PP_LW
+#undef PP_LW_
 #undef PP_LR
 #undef PP_LWAITF
 #undef PP_LF
@@ -1380,6 +1390,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 #undef PP_LWAIT
 #undef PP_PWAIT
 #undef PP_PW
+#undef PP_PW_
 #undef PP_PR
 #undef PP_PF
 #undef PP_ISS_COND

@@ -210,7 +210,10 @@ class Trainer:
     def save_checkpoint(self, path):
         if self.rank != 0:
             return
-        state = {'epoch': self.current_epoch, 'global_step': self.global_step, 'state_dict': self.model.state_dict(),
+        # Lightning 1.3.8 (the reference's pin) stores current_epoch + 1 and resumes at that value: same convention here, so a
+        # reference-written last_checkpoint.pth neither skips nor repeats an epoch ('callbacks' is not written: no callback state)
+        state = {'epoch': self.current_epoch + 1, 'global_step': self.global_step, 'state_dict': self.model.state_dict(),
+                 'pytorch-lightning_version': '1.3.8',
                  'optimizer_states': [self.optimizer.state_dict()],
                  'lr_schedulers': [self.scheduler.state_dict() if self.scheduler is not None else None]}
         tmp = path + '.tmp'
@@ -223,7 +226,7 @@ class Trainer:
         self.optimizer.load_state_dict(state['optimizer_states'][0])
         if self.scheduler is not None and state['lr_schedulers'][0] is not None:
             self.scheduler.load_state_dict(state['lr_schedulers'][0])
-        self.current_epoch = int(state['epoch']) + 1
+        self.current_epoch = int(state['epoch'])
         self.global_step = int(state.get('global_step', 0))
         from vtx import functions
         functions.clear_weight_cache()
@@ -237,6 +240,8 @@ class Trainer:
         loss = out['loss']
         loss.backward()
         self.buckets.finish()                                   # every bucket's mean all-reduce has landed in .grad
+        if hasattr(self.optimizer, 'set_skipped'):              # parameters outside this step's graph take no update (no decay)
+            self.optimizer.set_skipped(self.buckets.unfired())
         model.on_after_backward()
         model.optimizer_step(self.current_epoch, batch_idx, self.optimizer, 0, None, False, True, False)
         self.global_step += 1
@@ -378,10 +383,15 @@ def single_run(argv=None):
     data = SyntheticBatches(args, args.synthetic_steps, device, rank) if args.synthetic_steps > 0 else _reference_data_module(args)
     try:
         trainer.fit(model, data)
-    finally:
+    except BaseException:
+        # no barrier on the error path: the peers sit in a gradient all-reduce, a barrier here would hang until the backend's
+        # timeout and hide the exception -- tear the group down and let the launcher end the other ranks
         if dist.is_initialized():
-            dist.barrier()
             dist.destroy_process_group()
+        raise
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
     return trainer
 
 

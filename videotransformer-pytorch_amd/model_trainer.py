@@ -96,7 +96,8 @@ class Accuracy:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             st = torch.stack([self.correct.float(), torch.tensor(float(self.total), device=self.correct.device)])
-            dist.all_reduce(st)
+            from vtx import dp
+            dp.all_reduce_sum(st)                       # (staged through host memory when the backend is not RCCL)
             return st[0] / st[1].clamp(min=1.0)
         return self.correct.float() / max(self.total, 1)
 

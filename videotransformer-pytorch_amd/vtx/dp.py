@@ -159,6 +159,10 @@ class GradBuckets:
                     b['flat'].div_(self.world)
         self._launched = []
 
+    def unfired(self):
+        """The parameters whose gradient has NOT arrived since zero(): unused in this step's graph (their .grad view is all zero)."""
+        return [p for b in self.buckets for p in b['params'] if id(p) not in self._fired]
+
     def remove(self):
         for h in self._hooks:
             h.remove()

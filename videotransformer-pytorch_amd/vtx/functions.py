@@ -499,7 +499,9 @@ def _compaction_plan(scale_vec, n_units, rows_per, device):
     (kept count, dropped count, largest step of the keep / drop tables, device buffer [keep table | drop table | scales of
     the kept clips]); _plan_maps() turns the buffer into row maps."""
     host = getattr(scale_vec, '_vtx_host', None) if scale_vec is not None else None
-    if not _compact or host is None or host.numel() != n_units:
+    # (table row maps are for groups of >= 256 rows: the GEMM tile maps assume at most one group boundary per 256-row tile and
+    # read one spare table entry; a short-sequence model keeps the compute-and-multiply-by-zero path)
+    if not _compact or host is None or host.numel() != n_units or rows_per < 256:
         return None
     hv = host.numpy()
     kept = [i for i in range(n_units) if hv[i] != 0.0]
@@ -514,9 +516,6 @@ def _compaction_plan(scale_vec, n_units, rows_per, device):
     words = np.concatenate([np.asarray(tk, np.int32).view(np.float32), np.asarray(td, np.int32).view(np.float32),
                             np.asarray([hv[i] for i in kept], np.float32)])
     buf = ops.upload_f32(torch.from_numpy(words), device)
-    ik = buf[:len(tk)].view(torch.int32)
-    idr = buf[len(tk):len(tk) + len(td)].view(torch.int32)
-    sv_k = buf[len(tk) + len(td):]
     step = lambda t: max([b - a for a, b in zip(t, t[1:])] + [0])      # noqa: E731
     return len(kept), len(drop), step(tk), step(td), buf
 

@@ -25,13 +25,24 @@ class _FusedBase(torch.optim.Optimizer):
         self.last_grad_norm = None                      # device scalar: ||(per-parameter norms)||_2 of the last step
         self._key = None
         self._n_steps = 0
+        self._skipped = frozenset()                     # id() of parameters that take no update (see set_skipped)
+
+    def set_skipped(self, params):
+        """Parameters that received NO gradient in the step at hand.  With gradient buckets every ``p.grad`` is a (zero-filled)
+        view that is never None, so "unused this step" has to be said explicitly: torch's optimizers skip ``grad is None``
+        parameters altogether -- no weight decay, no momentum update -- and so does the step after this call (the reference runs
+        DDP with find_unused_parameters=True for such models, model_pretrain.py:200-204)."""
+        ids = frozenset(id(p) for p in params)
+        if ids != self._skipped:
+            self._skipped = ids
+            self._key = None
 
     # ---- device tables --------------------------------------------------------------------------
     def _entries(self):
         ent = []
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
-                if p.grad is None:
+                if p.grad is None or id(p) in self._skipped:
                     continue
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
                     raise TypeError('vtx.optim: parameters and gradients must be float32')
@@ -106,7 +117,8 @@ class _FusedBase(torch.optim.Optimizer):
         self._bump_versions()
         # the staged bf16 W / W^T copies of the updated weights: one launch now instead of one per weight in the next forward
         from . import functions
-        functions.restage_weights([p for g in self.param_groups for p in g['params'] if p.grad is not None and p.ndim >= 2])
+        functions.restage_weights([p for g in self.param_groups for p in g['params']
+                                   if p.grad is not None and p.ndim >= 2 and id(p) not in self._skipped])
         return loss
 
     def _bump_versions(self):
@@ -132,8 +144,10 @@ class _FusedBase(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd['state'].values():
-            st['step'] = torch.tensor(float(self._n_steps))
+        # torch packs the LIVE per-parameter dicts by reference: add the 'step' entry to shallow copies, or every save would leave
+        # a stale key in the optimizer's own state.  One tensor PER parameter: torch.optim.AdamW increments each parameter's
+        # 'step' in place after loading such a dict -- a shared tensor would count every parameter's update.
+        sd['state'] = {k: {**v, 'step': torch.tensor(float(self._n_steps))} for k, v in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):
