@@ -69,7 +69,8 @@ const char* vtx_last_error_string(void);
  * continuous-flow kernels, 5 = lean passes (the default, same as 0), 6 = lean passes with the first four of every tile rolled
  * into its last K tile -- 4 / 5 / 6 give identical results), "pp_cont" = 0|1 (continuous flow of the persistent GEMM: the
  * next tile's first K tiles are requested inside the current main loop; 1 by default, 0 = per-tile prologue; identical
- * results), "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown
+ * results), "ln_rows" = 1 .. 4 (rows per trip of the LayerNorm forward kernel, default 3; identical results),
+ * "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown
  * name or value. */
 int vtx_set_option(const char* name, const char* value);
 

@@ -109,6 +109,32 @@ def test_layernorm_fwd_bwd(dtype, D):
     check(f'ln_bwd dbeta {dtype} D={D}', db.cpu(), bq.grad, TOL[dtype])
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('D', [128, 200, 768, 1024])
+def test_layernorm_fwd_rows_per_trip(dtype, D, vtx_opts):
+    """The forward kernel with 2 / 3 / 4 rows per trip (all rows requested before the first is reduced; the default is 3)
+    against the one-row-per-wave kernel: the same arithmetic per row -- bit-identical outputs and statistics --, row counts
+    that do not divide by the rows per trip, row maps on input and output, D that is and is not a multiple of 256."""
+    from vtx import ops
+    B, N = 5, 43                                    # 215 rows
+    x = dev(rnd(B, 1 + N, D, seed=1) * 2 + 0.5, dtype)
+    gamma, beta = dev(1 + 0.1 * rnd(D, seed=2)), dev(0.1 * rnd(D, seed=3))
+    tm = ops.tokmap(N)
+    outs = []
+    for nr in ('1', '2', '3', '4'):
+        vtx_opts('ln_rows', nr)
+        y = torch.zeros(B, 1 + N, D, dtype=dtype, device=DEV)
+        mean, rstd = torch.zeros(B * N, device=DEV), torch.zeros(B * N, device=DEV)
+        ops.layernorm_fwd(x, B * N, D, D, tm, gamma, beta, 1e-5, y, D, mean=mean, rstd=rstd, ymap=tm)
+        outs.append((y, mean, rstd))
+    xq = x.double().cpu()[:, 1:]
+    ref = torch.nn.functional.layer_norm(xq, (D,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    check(f'ln_fwd rows-per-trip {dtype} D={D}', outs[2][0].float().cpu()[:, 1:], ref, TOL[dtype])
+    assert not outs[2][0][:, 0].any(), 'a cls row (skipped by the output map) was written'
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), f'{dtype} D={D}'
+
+
 # --------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('variant', ['pp256', 'ring256x3', 'ring256x3k32', 'ring256x4k32', 'ring128x3', 'ring128x4k32', 'dma2'])
 def test_gemm_nt_bf16_variants(variant, vtx_opts):

@@ -51,6 +51,7 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }
   if (strcmp(name, "pp_epi") == 0) { o.pp_epi = atoi(value); return VTX_OK; }
   if (strcmp(name, "pp_cont") == 0) { o.pp_cont = atoi(value) != 0; return VTX_OK; }
+  if (strcmp(name, "ln_rows") == 0) { const int g = atoi(value); if (g < 1 || g > 4) return VTX_EINVAL; o.ln_rows = g; return VTX_OK; }
   if (strcmp(name, "pp_trace") == 0) { o.pp_trace = strtoull(value, nullptr, 0); return VTX_OK; }
   return VTX_EINVAL;
 }
@@ -61,7 +62,7 @@ Options& options() {
     static const char* const env[][2] = {{"VTX_GEMM_NT", "gemm_nt"}, {"VTX_GEMM_TN", "gemm_tn"}, {"VTX_GEMM_NODMA", "gemm_nodma"},
                                          {"VTX_TN_SAFE", "tn_safe"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
                                          {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"},
-                                         {"VTX_GEMM_PP_CONT", "pp_cont"}, {"VTX_ATTN_HW_FWD", "attn_hw_fwd"}, {"VTX_ATTN_HW_BWD", "attn_hw_bwd"}, {"VTX_ATTN_DKV", "attn_dkv"},
+                                         {"VTX_GEMM_PP_CONT", "pp_cont"}, {"VTX_LN_ROWS", "ln_rows"}, {"VTX_ATTN_HW_FWD", "attn_hw_fwd"}, {"VTX_ATTN_HW_BWD", "attn_hw_bwd"}, {"VTX_ATTN_DKV", "attn_dkv"},
                                          {"VTX_ATTN_FUSED", "attn_fused"}};
     for (const auto& e : env) {
       const char* v = getenv(e[0]);

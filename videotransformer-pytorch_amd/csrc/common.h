@@ -175,6 +175,7 @@ struct Options {
   int attn_fused = 1;        // VTX_ATTN_FUSED: backward of the 33..224-token attention as one kernel (dq, dk, dv from one pass over HBM); 0 = dq + dkv kernels
   int attn_dkv = 3;          // VTX_ATTN_DKV: dk / dv kernel of the 197-token attention: 0 = run-time query-tile loop, 1..4 = unrolled variants
                              // (3 = unrolled, next key tile loaded behind the current one: profiles/round3_attn_dkv_variants.txt)
+  int ln_rows = 3;           // VTX_LN_ROWS: rows per trip of the LayerNorm forward kernel (1 = one row per wave, the round-1 kernel; 2 .. 4: ln_fwd2_kernel)
   int pp_grid = 256;         // VTX_GEMM_PP_GRID: resident workgroups of the persistent NT GEMM
   int pp_cg = 0;             // VTX_GEMM_PP_CG: column tiles per group (0: from K)
   int pp_epi = 0;            // VTX_GEMM_PP_EPI: 1 = per-pass epilogue (A/B timing); 2 / 3 = diagnostics: no stores / no staging

@@ -132,6 +132,94 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(
   }
 }
 
+// NR rows per trip (option ln_rows = 2 .. 4, default 3; round 4): the raw segments of ALL NR rows are requested before the
+// first one is reduced, as in the backward kernel below.  FULL (D == 256 NCH) is a template flag so that the row loop carries no
+// exec-masked load -- with one in it hipcc waits vmcnt(0) per load and the later rows' requests do not overlap the first row's
+// reductions, which is why round 2's "next row prefetched" / "two rows per trip" experiments on the kernel above (whose `col < D`
+// is a run-time predicate) measured SLOWER.  Same arithmetic per row: bit-identical outputs.  150 624 rows of 768 bf16, same box,
+// interleaved: 95.5 us (one row per wave) -> 79.8 / 76.3 / 77.3 us for NR = 2 / 3 / 4 = 6.06 TB/s at NR = 3 (0.76 of 8 TB/s,
+// the streaming-copy rate of this chip is ~6.3); 12 552 rows (8 clips): 18.5 -> 11.2 us; D = 1024: 202 -> 115 us.  A variant with
+// 16 bytes per lane and access (1.5 accesses per 768-wide row) measured 124 us and was dropped.
+template <typename T, int NCH, bool FULL, int NR>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd2_kernel(
+    int rows, int D, const T* __restrict__ x, long ldx, vtx_rowmap xmap,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    T* __restrict__ y, long ldy, vtx_rowmap ymap, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+  typedef typename Raw4<T>::type raw_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long total_waves = (long)gridDim.x * LN_WAVES;
+  const float invD = 1.0f / (float)D;
+  float gm[NCH][4], bt[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = 4 * (lane + 64 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[c][j] = (FULL || col < D) ? gamma[col + j] : 0.f;
+      bt[c][j] = (FULL || col < D) ? beta[col + j] : 0.f;
+    }
+  }
+  struct Row { raw_t x[NCH]; };
+  auto fetch = [&](long r, Row& w) {
+    const T* xr = x + map_row(xmap, r) * ldx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) w.x[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(xr + col));
+    }
+  };
+  auto finish = [&](long r, const Row& w) {
+    float v[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+        unpack4(w.x[c], v[c]);
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+      } else {
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+      }
+    }
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mu; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+    T* yr = y + map_row(ymap, r) * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rstd * gm[c][j] + bt[c][j];
+        st4<T>(yr + col, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[r] = mu;
+      if (rstd_out) rstd_out[r] = rstd;
+    }
+  };
+  for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += NR * total_waves) {
+    Row w[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) fetch(r + i * total_waves < rows ? r + i * total_waves : r, w[i]);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i == 0 || r + i * total_waves < rows) finish(r + i * total_waves, w[i]);
+  }
+}
+
 // Backward.  Each wave walks rows r = w, w + W, ...; per-lane column partials of
 // dgamma/dbeta stay in registers, are combined across the block's 4 waves in
 // LDS and written to part[block][2][D]; reduce_partials_kernel finishes.
@@ -421,6 +509,18 @@ static int ln_fwd_t(int rows, int D, const void* x, long ldx, vtx_rowmap xmap, c
                     float* rstd, hipStream_t st) {
   const int nch = cdiv(D, 256);
   dim3 g(ln_blocks(rows)), b(LN_WAVES * 64);
+  if (options().ln_rows >= 2 && nch <= 4) {            // NR rows per trip, all requested before the first is reduced
+    const int nr = options().ln_rows;
+    dim3 g2(ln_blocks((rows + nr - 1) / nr));
+#define LN_FWD2_(N, R)                                                                             \
+    { if (D == N * 256) hipLaunchKernelGGL((ln_fwd2_kernel<T, N, true, R>), g2, b, 0, st, rows, D, (const T*)x, ldx, xmap, gamma, beta, eps, (T*)y, ldy, ymap, mean, rstd); \
+      else hipLaunchKernelGGL((ln_fwd2_kernel<T, N, false, R>), g2, b, 0, st, rows, D, (const T*)x, ldx, xmap, gamma, beta, eps, (T*)y, ldy, ymap, mean, rstd); }
+#define LN_FWD2(N) { if (nr == 2) LN_FWD2_(N, 2) else if (nr == 3) LN_FWD2_(N, 3) else LN_FWD2_(N, 4) }
+    if (nch == 1) LN_FWD2(1) else if (nch == 2) LN_FWD2(2) else if (nch == 3) LN_FWD2(3) else LN_FWD2(4)
+#undef LN_FWD2
+#undef LN_FWD2_
+    return check_launch("layernorm_fwd2");
+  }
 #define LN_FWD(N)                                                                                  \
   hipLaunchKernelGGL((ln_fwd_kernel<T, N>), g, b, 0, st, rows, D, (const T*)x, ldx, xmap, gamma,   \
                      beta, eps, (T*)y, ldy, ymap, mean, rstd)
