@@ -208,6 +208,12 @@ int vtx_attn_bwd(const vtx_attn_bwd_desc* d, void* stream);
 /* out[b,0,:] = x[b,0,:] + mean_t a_cls[b*T+t,:]   (transformer.py:371-377) */
 int vtx_cls_mean_fwd(int dtype, int B, int T, int D, const void* a_cls, long lda,
                      const void* x, void* out, long ld_tok, long rows_per_clip, void* stream);
+/* ViViT fact_encoder glue (video_transformer.py:511-525): x [(B T), 1 + P, D] -> h [B, 1 + T, D],
+ * h[i, 0] = x[i, 0] + e[0] (row i of the FLATTENED (b t) axis, as the reference's `x[:b, 0]` reads it),
+ * h[i, 1 + t] = mean_p x[i T + t, 1 + p] + e[1 + t];  e = time_embed [1 + T, D] fp32.  Backward: dx, d_time_embed (+)=. */
+int vtx_fact_glue_fwd(int dtype, int B, int T, int P, int D, const void* x, const float* time_embed, void* h, void* stream);
+int vtx_fact_glue_bwd(int dtype, int B, int T, int P, int D, const void* dh, void* dx, float* d_time_embed, int accumulate,
+                      void* stream);
 /* da[0:B*N]   = dout[b,1+n] * s[b*T + n%T];  da[B*N + b*T+t] = dout[b,0] * s[b*T+t] / T
  * (backward of transformer.py:367-377; s may be NULL = 1) */
 int vtx_space_grad_prep(int dtype, int B, int T, int P, int D, const void* dout, long ld,

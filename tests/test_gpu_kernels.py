@@ -135,6 +135,32 @@ def test_layernorm_fwd_rows_per_trip(dtype, D, vtx_opts):
         assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), f'{dtype} D={D}'
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_fact_glue_fwd_bwd(dtype):
+    """vtx_fact_glue_fwd / _bwd against the reference's expressions (video_transformer.py:515-523), the `x[:b, 0]` quirk
+    included: the cls rows of the temporal encoder's input are the first b rows of the flattened (b t) axis."""
+    from vtx import ops
+    b, T, P, D = 3, 5, 14, 128
+    x = rnd(b * T, 1 + P, D, seed=1)
+    e = rnd(1, 1 + T, D, seed=2)
+    dh = rnd(b, 1 + T, D, seed=3)
+    xq = q(x, dtype).requires_grad_(True)
+    eq = e.double().requires_grad_(True)
+    cls_tokens = xq[:b, 0, :].unsqueeze(1)
+    frames = xq[:, 1:, :].reshape(b, T, P, D).mean(2)
+    ref = torch.cat((cls_tokens, frames), dim=1) + eq
+    ref.backward(q(dh, dtype))
+    h = ops.fact_glue_fwd(dev(x, dtype), dev(e).reshape(1 + T, D), b, T, P, D)
+    check(f'fact_glue fwd {dtype}', h.float().cpu(), ref.detach(), TOL[dtype])
+    de = torch.full((1 + T, D), float('nan'), device=DEV)
+    dx = ops.fact_glue_bwd(dev(dh, dtype), b, T, P, D, d_time_embed=de)
+    check(f'fact_glue dx {dtype}', dx.float().cpu(), xq.grad, TOL[dtype])
+    check(f'fact_glue d_time_embed {dtype}', de.cpu(), eq.grad.reshape(1 + T, D), 1e-5)
+    de2 = torch.ones(1 + T, D, device=DEV)
+    ops.fact_glue_bwd(dev(dh, dtype), b, T, P, D, d_time_embed=de2, accumulate=True)
+    check(f'fact_glue d_time_embed accumulate {dtype}', de2.cpu(), eq.grad.reshape(1 + T, D) + 1, 1e-5)
+
+
 # --------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('variant', ['pp256', 'ring256x3', 'ring256x3k32', 'ring256x4k32', 'ring128x3', 'ring128x4k32', 'dma2'])
 def test_gemm_nt_bf16_variants(variant, vtx_opts):

@@ -126,6 +126,77 @@ __global__ void cls_mean_fwd_kernel(int B, int T_, int D, const T* __restrict__ 
   store8(out + (long)b * rows_per_clip * ld + c, acc);
 }
 
+// ---- ViViT fact_encoder: glue between the spatial and the temporal encoder (reference video_transformer.py:511-525) ----
+// x [(b t), 1 + P, D] -> h [b, 1 + T, D]:  h[i, 0] = x[i, 0] + e[0]   (the reference reads `x[:b, 0]` of the FLATTENED (b t) axis:
+// row i < b, i.e. frame i % T of clip i / T -- kept literal), h[i, 1 + t] = mean_p x[i T + t, 1 + p] + e[1 + t].
+// One workgroup per output row; the patch rows are summed in fp32 in two interleaved halves (p even / odd, fixed order) by
+// 16-byte loads.  e = time_embed [1 + T, D] fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void fact_glue_fwd_kernel(int B, int T_, int P, int D, const T* __restrict__ x, const float* __restrict__ e,
+                                                            T* __restrict__ h) {
+  __shared__ float part[2][2048];
+  const int row = blockIdx.x;                       // output row i * (1 + T) + s
+  const int i = row / (1 + T_), sidx = row - i * (1 + T_);
+  const int per = D / 8, half = threadIdx.x / per, cc = (threadIdx.x - half * per) * 8;
+  const long rs = (long)(1 + P) * D;                // elements per (b t) row block of x
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half < 2) {
+    if (sidx == 0) {
+      if (half == 0) load8(x + (long)i * rs + cc, acc);
+    } else {
+      const T* src = x + ((long)i * T_ + (sidx - 1)) * rs + D + cc;      // patch 0 of frame (i, s - 1)
+      for (int p = half; p < P; p += 2) {
+        float v[8];
+        load8(src + (long)p * D, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[half][cc + j] = acc[j];
+  }
+  __syncthreads();
+  if (half == 0) {
+    float o[8];
+    const float inv = sidx == 0 ? 1.0f : 1.0f / (float)P;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (part[0][cc + j] + part[1][cc + j]) * inv + e[(long)sidx * D + cc + j];
+    store8(h + (long)row * D + cc, o);
+  }
+}
+// backward: dx[(i T + t), 1 + p] = dh[i, 1 + t] / P;  dx[r, 0] = r < B ? dh[r, 0] : 0;  de[s] (+)= sum_i dh[i, s] (fp32, i ascending)
+template <typename T>
+__global__ __launch_bounds__(256) void fact_glue_bwd_kernel(int B, int T_, int P, int D, const T* __restrict__ dh, T* __restrict__ dx) {
+  const long per = D / 8;
+  const long total = (long)B * T_ * (1 + P) * per;
+  const float inv = 1.0f / (float)P;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / per;                       // row of x: (frame f = i T + t, token q)
+    const int cc = (int)(idx - r * per) * 8;
+    const long f = r / (1 + P);
+    const int q = (int)(r - f * (1 + P));
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q == 0) {
+      if (f < B) load8(dh + f * (1 + T_) * D + cc, v);
+    } else {
+      const long i = f / T_, t = f - i * T_;
+      load8(dh + (i * (1 + T_) + 1 + t) * D + cc, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= inv;
+    }
+    store8(dx + r * D + cc, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fact_glue_de_kernel(int B, int T_, int D, const T* __restrict__ dh, float* __restrict__ de, int accumulate) {
+  const long n = (long)(1 + T_) * D;
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  float a = 0.f;
+  for (int i = 0; i < B; ++i) a += ET<T>::ld(dh + (long)i * n + k);
+  de[k] = accumulate ? de[k] + a : a;
+}
+
 // ---- da rows for the spatial projection backward ----------------------------------
 template <typename T>
 __global__ void space_grad_prep_kernel(int B, int T_, int P, int D, const T* __restrict__ dout, long ld,
@@ -495,6 +566,39 @@ extern "C" int vtx_cls_mean_fwd(int dtype, int B, int T, int D, const void* a_cl
              hipLaunchKernelGGL(cls_mean_fwd_kernel<bf16raw>, grid, block, 0, st, B, T, D, (const bf16raw*)a_cls, lda, (const bf16raw*)x, (bf16raw*)out, ld_tok, rows_per_clip),
              "cls_mean_fwd");
   return check_launch("cls_mean_fwd");
+}
+
+extern "C" int vtx_fact_glue_fwd(int dtype, int B, int T, int P, int D, const void* x, const float* time_embed, void* h, void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && P > 0 && D > 0 && D % 8 == 0 && D <= 1024 && x && time_embed && h, VTX_EINVAL, "fact_glue_fwd: bad arguments");
+  VTX_REQUIRE(aligned16(x) && aligned16(h), VTX_EALIGN, "fact_glue_fwd: 16-byte alignment required");
+  dim3 grid(B * (1 + T)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(fact_glue_fwd_kernel<float>, grid, block, 0, st, B, T, P, D, (const float*)x, time_embed, (float*)h),
+             hipLaunchKernelGGL(fact_glue_fwd_kernel<bf16raw>, grid, block, 0, st, B, T, P, D, (const bf16raw*)x, time_embed, (bf16raw*)h),
+             "fact_glue_fwd");
+  return check_launch("fact_glue_fwd");
+}
+
+extern "C" int vtx_fact_glue_bwd(int dtype, int B, int T, int P, int D, const void* dh, void* dx, float* d_time_embed, int accumulate,
+                                 void* stream) {
+  VTX_REQUIRE(B > 0 && T > 0 && P > 0 && D > 0 && D % 8 == 0 && dh && dx, VTX_EINVAL, "fact_glue_bwd: bad arguments");
+  VTX_REQUIRE(aligned16(dh) && aligned16(dx), VTX_EALIGN, "fact_glue_bwd: 16-byte alignment required");
+  const long total = (long)B * T * (1 + P) * (D / 8);
+  dim3 grid(grid_for(total, 256)), block(256);
+  hipStream_t st = as_stream(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(fact_glue_bwd_kernel<float>, grid, block, 0, st, B, T, P, D, (const float*)dh, (float*)dx),
+             hipLaunchKernelGGL(fact_glue_bwd_kernel<bf16raw>, grid, block, 0, st, B, T, P, D, (const bf16raw*)dh, (bf16raw*)dx),
+             "fact_glue_bwd");
+  int rc = check_launch("fact_glue_bwd");
+  if (rc || !d_time_embed) return rc;
+  dim3 g2(cdiv((long)(1 + T) * D, 256));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(fact_glue_de_kernel<float>, g2, block, 0, st, B, T, D, (const float*)dh, d_time_embed, accumulate),
+             hipLaunchKernelGGL(fact_glue_de_kernel<bf16raw>, g2, block, 0, st, B, T, D, (const bf16raw*)dh, d_time_embed, accumulate),
+             "fact_glue_de");
+  return check_launch("fact_glue_de");
 }
 
 extern "C" int vtx_space_grad_prep(int dtype, int B, int T, int P, int D, const void* dout, long ld, const float* s,

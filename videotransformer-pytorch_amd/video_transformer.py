@@ -274,11 +274,7 @@ class ViViT(_VideoTransformerBase):
     def _fact_temporal_tokens(self, x, b):
         """Glue between the spatial and temporal encoders (reference :515-523), kept
         literal: the cls rows are the first b rows of the flattened (b t) axis."""
-        x32 = F_.CastFn.apply(x, torch.float32)
-        cls_b = x32[:b, 0:1]
-        frames = x32[:, 1:].reshape(b, -1, x32.shape[1] - 1, x32.shape[2]).mean(2)
-        h = torch.cat([cls_b, frames], dim=1) + _embed(self.time_embed, x.device)
-        return F_.CastFn.apply(h.contiguous(), vtx.compute_dtype())
+        return F_.FactGlueFn.apply(x, _embed(self.time_embed, x.device), b)
 
     def forward(self, x):
         x, cls_tokens, b = self.prepare_tokens(x)

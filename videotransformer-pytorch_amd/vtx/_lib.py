@@ -124,6 +124,8 @@ SIGNATURES = {
     'vtx_attn_fwd': (ci, [C.POINTER(AttnDesc), vp]),
     'vtx_attn_bwd': (ci, [C.POINTER(AttnBwdDesc), vp]),
     'vtx_cls_mean_fwd': (ci, [ci, ci, ci, ci, vp, cl, vp, vp, cl, cl, vp]),
+    'vtx_fact_glue_fwd': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_fact_glue_bwd': (ci, [ci, ci, ci, ci, ci, vp, vp, vp, ci, vp]),
     'vtx_space_grad_prep': (ci, [ci, ci, ci, ci, ci, vp, cl, vp, vp, cl, vp]),
     'vtx_cls_qkv_reduce': (ci, [ci, ci, ci, ci, vp, cl, vp, cl, cl, vp]),
     'vtx_dropped_rows_fix': (ci, [ci, cl, ci, ci, vp, vp, cl, RowMap, vp, vp, cl, RowMap, vp, cl, vp]),

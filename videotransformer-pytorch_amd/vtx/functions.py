@@ -868,6 +868,30 @@ class LinearFn(torch.autograd.Function):
         return dx, d_w[:N], d_b
 
 
+class FactGlueFn(torch.autograd.Function):
+    """ViViT fact_encoder: spatial-encoder output x [(b t), 1 + P, D] -> temporal-encoder input [b, 1 + T, D]: the cls rows are
+    the first b rows of the flattened (b t) axis (the reference's `x[:b, 0]`, video_transformer.py:515, kept literal), a frame's
+    token is the mean over its patches (:516-517), plus time_embed (:519-523).  One kernel forward (vtx_fact_glue_fwd), one + the
+    time_embed reduction backward -- round 3 did this with cast / reshape / mean / cat / add in ATen."""
+
+    @staticmethod
+    def forward(ctx, x, time_embed, b):
+        x = _chk(x)
+        BT, P1, D = x.shape
+        T = BT // b
+        ctx.cfg = (b, T, P1 - 1, D, time_embed.shape)
+        return ops.fact_glue_fwd(x, time_embed.reshape(1 + T, D), b, T, P1 - 1, D)
+
+    @staticmethod
+    def backward(ctx, dh):
+        b, T, P, D, e_shape = ctx.cfg
+        dh = _chk(dh)
+        need_e = ctx.needs_input_grad[1]
+        de = torch.empty(1 + T, D, dtype=torch.float32, device=dh.device) if need_e else None
+        dx = ops.fact_glue_bwd(dh, b, T, P, D, d_time_embed=de)
+        return dx, (de.reshape(e_shape) if need_e else None), None
+
+
 class CastFn(torch.autograd.Function):
     """dtype boundary of the path: compute dtype <-> float32."""
 

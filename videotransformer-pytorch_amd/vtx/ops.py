@@ -325,6 +325,21 @@ def attn_bwd(qkv, out, lse, dout, dqkv, mode, S, L, H, hd, scale, B=0, T=0, P=0,
 
 
 # ------------------------------------------------------------------- glue ops
+def fact_glue_fwd(x, time_embed, B, T, P, D):
+    """ViViT fact_encoder glue: x [(B T), 1 + P, D] -> h [B, 1 + T, D] (vtx_fact_glue_fwd)."""
+    need_cuda(x, time_embed)
+    h = torch.empty(B, 1 + T, D, dtype=x.dtype, device=x.device)
+    call('vtx_fact_glue_fwd', dt(x), B, T, P, D, ptr(x), ptr(_f32(time_embed)), ptr(h), stream())
+    return h
+
+
+def fact_glue_bwd(dh, B, T, P, D, d_time_embed=None, accumulate=False):
+    need_cuda(dh)
+    dx = torch.empty(B * T, 1 + P, D, dtype=dh.dtype, device=dh.device)
+    call('vtx_fact_glue_bwd', dt(dh), B, T, P, D, ptr(dh), ptr(dx), ptr(d_time_embed), int(bool(accumulate)), stream())
+    return dx
+
+
 def cls_mean_fwd(a_cls, x, out, B, T, D, rows_per_clip):
     call('vtx_cls_mean_fwd', dt(x), B, T, D, ptr(a_cls), D, ptr(x), ptr(out), D, rows_per_clip, stream())
 
