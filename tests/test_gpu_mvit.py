@@ -299,7 +299,7 @@ def test_maskfeat_mvit_b_full_size_bf16():
         assert abs(pf.norm().item() - float(g['pred_n'][0])) <= 1e-2 * float(g['pred_n'][0])
         assert abs(float(loss.detach()) - float(g['loss'])) <= 1e-2 * float(g['loss'])
         typical = float(g['typical_norm'])
-        ours, theirs, n = [], [], 0
+        ours, theirs, n, large = [], [], 0, []
         for k, p in m.named_parameters():
             got = p.grad.detach().double().cpu().flatten()
             if 'zero:' + k in g.files:
@@ -318,6 +318,13 @@ def test_maskfeat_mvit_b_full_size_bf16():
             if e > bar:
                 report(f'FAIL MaskFeat/MViT-B bf16 grad {k}: l2-rel={e:.3e} bar={bar:.3e} (autocast {ae:.3e})')
             assert e <= bar, (k, e, bar, ae)
+            if e > 5e-2:
+                # every tensor whose RELATIVE error is large is named, with the size of the reference gradient next to the
+                # typical parameter gradient of the model: a relative figure only means something when the tensor has a gradient
+                rn = (ref.norm().item() if 'g:' + k in g.files else gn)
+                report(f'note MaskFeat/MViT-B bf16 grad {k}: l2-rel {e:.3e} (oracle under autocast {ae:.3e}); |ref| = {rn:.3e} = '
+                       f'{rn / typical:.2e} x the typical gradient norm; absolute error {e * rn / typical:.2e} x typical')
+                large.append((k, e, ae, rn / typical))
             ours.append(e)
             theirs.append(ae)
             n += 1
@@ -325,5 +332,37 @@ def test_maskfeat_mvit_b_full_size_bf16():
         report(f'ok   MaskFeat/MViT-B bf16 full size: pred {e_pred:.3e}, {n} gradients, median l2 {mo:.3e} vs oracle-autocast median '
                f'{mt:.3e}, worst {max(ours):.3e} (oracle-autocast worst {max(theirs):.3e})')
         assert mo <= 1.25 * mt, (mo, mt)
+        report(f'MaskFeat/MViT-B bf16: {len(large)} of {n} gradients above 5e-2 relative: ' + ', '.join(f'{k} ({e:.2e}; |ref| {r:.1e} x typical)' for k, e, _, r in large))
+        # a 34 % gradient error must not pass on the strength of an unpinned oracle alone.  What it is (and is not):
+        # exactly ONE tensor is above 5e-2, pos_embed_spatial, and its gradient is LARGE (11 x the typical norm), so this is no
+        # vanishing / cancelling gradient.  It is d(loss)/d(backbone input) summed over the 8 frames only (one clip), i.e. an
+        # 8-term sum per element of a quantity that 16 blocks of bf16 arithmetic with this case's synthetic weights have
+        # already made ~35 % wrong ELEMENT-WISE -- in every bf16 implementation: the oracle graph under torch.autocast shows
+        # 0.359 on the same tensor, and the check below measures it inside THIS library, between its own exact-fp32 path (which
+        # matches the float64 oracle to 1e-6, test_maskfeat_as_the_reference_trainer_builds_it) and its bf16 path.  Every
+        # parameter that averages the same input gradient over thousands of tokens (stem convolution, temporal / class position
+        # embeddings, mask token) is inside 5e-2.  So: the flagged tensors must be sums of FEW input-gradient terms and must
+        # not be worse than the element-wise input gradient itself.
+        if large:
+            def input_grad(prec):
+                vtx.set_precision(prec)
+                mm, _, _ = _maskfeat_full()
+                cap = {}
+                def fwd_hook(mod, inp, out):            # (returns None: a forward hook's return value would replace the output)
+                    out.register_hook(lambda gr: cap.__setitem__('g', gr.detach().double().cpu()))
+                h = mm.mvit.cls_positional_encoding.register_forward_hook(fwd_hook)
+                _, ls = mm(x.to(DEV), target.to(DEV), mask.to(DEV), markers)
+                ls.backward()
+                h.remove()
+                return cap['g'], mm.mvit.cls_positional_encoding.pos_embed_spatial.grad.detach().double().cpu()
+            dx16, ps16 = input_grad('bf16')
+            dx32, ps32 = input_grad('fp32')
+            e_dx = (dx16 - dx32).norm().item() / dx32.norm().item()
+            e_ps = (ps16 - ps32).norm().item() / ps32.norm().item()
+            report(f'MaskFeat/MViT-B: input gradient d(loss)/d(tokens) bf16 path vs fp32 path of this library: l2-rel {e_dx:.3e}; '
+                   f'pos_embed_spatial (its sum over 8 frames) bf16 vs fp32 path: {e_ps:.3e}')
+            for k, e, ae, r in large:
+                assert k.endswith('pos_embed_spatial'), f'{k}: {e:.3e} relative with |ref| = {r:.2e} x typical -- not a known short sum of input gradients'
+                assert e <= 1.25 * e_dx, (k, e, e_dx)
     finally:
         vtx.set_precision('auto')
