@@ -10,9 +10,11 @@ for db in glob.glob(sys.argv[1] + '/**/*.db', recursive=True):
     for name, cn, v in c.execute(f"select {kn}, counter_name, value from {view}"):
         if not any(k in name for k in ('gemm', 'attn', 'ln_', 'wprod')):
             continue
-        a = acc[(name.split('(')[0][-48:], cn)]
+        short = name.split('(')[0]
+        short = short[short.index('vtx::') + 5:] if 'vtx::' in short else short      # kernel name with its template arguments
+        a = acc[(short[-72:], cn)]
         a[0] += v; a[1] += 1
     # values are summed over dimensions per dispatch row; report mean per dispatch
     disp = collections.defaultdict(int)
     for (k, cn), (s, n) in sorted(acc.items()):
-        print(f'{k:50s} {cn:32s} total={s:.4g} rows={n}')
+        print(f'{k:74s} {cn:32s} total={s:.4g} rows={n}')
