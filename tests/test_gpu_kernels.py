@@ -724,6 +724,61 @@ def test_attention_mfma_matches_valu(S, L, vtx_opts):
     check(f'attn mfma vs valu dqkv S={S} L={L}', res['0'][2], res['1'][2], 2e-2)
 
 
+@pytest.mark.parametrize('mode,S,L,H', [('contig', 3, 197, 3), ('contig', 2, 224, 2), ('contig', 1, 193, 1), ('contig', 70, 197, 12),
+                                        ('space', 0, 197, 3), ('space', 0, 211, 12)])
+def test_attention_backward_streamed_one_phase(mode, S, L, H, vtx_opts):
+    """attn_fused=2 (193..224 tokens): one phase per (sequence, head) -- a wave owns a key tile, dS goes through LDS once for
+    the dq product, the seven partial dq tiles are summed in fixed order.  dk / dv: the same products in the same order as the
+    other kernels (bit-identical); dq: equal up to the fp32 rounding of a different summation order (then one bf16 rounding);
+    run-to-run bit-reproducible; 840 items = several per workgroup (ring refill, parity of the lse / delta buffers)."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG, ATTN_SPACE
+    hd = 64
+    D = H * hd
+    bf = torch.bfloat16
+    if mode == 'contig':
+        qkv = dev(rnd(S, L, 3 * D, seed=L) * 1.5, bf)
+        do = dev(rnd(S, L, D, seed=L + 1), bf)
+        args = (ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        new_out = lambda: torch.empty(S, L, D, dtype=bf, device=DEV)                      # noqa: E731
+        nlse = S * H * L
+        new_dqkv = lambda: (torch.full((S, L, 3 * D), float('nan'), dtype=bf, device=DEV), None)   # noqa: E731
+    else:
+        B, T, P = (2, 3, L - 1) if H == 3 else (6, 8, L - 1)
+        N = P * T
+        qkv = dev(rnd(B, 1 + N, 3 * D, seed=L) * 1.5, bf)
+        do = dev(rnd(B * N + B * T, D, seed=L + 1), bf)
+        args = (ATTN_SPACE, B * T, L, H, hd, hd ** -0.5, B, T, P)
+        new_out = lambda: torch.empty(B * N + B * T, D, dtype=bf, device=DEV)             # noqa: E731
+        nlse = B * T * H * L
+        new_dqkv = lambda: (torch.zeros(B, 1 + N, 3 * D, dtype=bf, device=DEV),           # noqa: E731
+                            torch.full((B * T, 3 * D), float('nan'), dtype=bf, device=DEV))
+    o = new_out()
+    lse = torch.empty(nlse, device=DEV)
+    ops.attn_fwd(qkv, o, lse, *args)
+    res = []
+    for fused in ('1', '2', '2'):
+        vtx_opts('attn_fused', fused)
+        dqkv, dcls = new_dqkv()
+        if dcls is None:
+            ops.attn_bwd(qkv, o, lse, do, dqkv, *args)
+        else:
+            ops.attn_bwd(qkv, o, lse, do, dqkv, *args, dqkv_cls=dcls)
+        torch.cuda.synchronize()
+        res.append((dqkv, dcls))
+    (ref, rcls), (got, gcls), (again, acls) = res
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, again) and (gcls is None or torch.equal(gcls, acls))
+    for a, b in ((got, ref),) + (((gcls, rcls),) if gcls is not None else ()):
+        a3, b3 = a.view(-1, 3, D), b.view(-1, 3, D)
+        assert torch.equal(a3[:, 1:], b3[:, 1:]), 'dk / dv must be bit-identical'
+        dq, rq = a3[:, 0].float(), b3[:, 0].float()
+        # one bf16 ulp where the fp32 sums round differently: |diff| <= 2^-7 |ref| (+ tiny absolute), on few elements
+        diff = (dq - rq).abs()
+        assert (diff <= rq.abs() * 2 ** -7 + 1e-6).all(), float(diff.max())
+        assert (diff > 0).float().mean() < 0.05
+
+
 @pytest.mark.parametrize('mode,S,L,H', [('contig', 3, 197, 3), ('contig', 5, 33, 2), ('contig', 2, 224, 2), ('contig', 4, 130, 12),
                                         ('space', 0, 197, 3), ('space', 0, 37, 2), ('contig', 2, 256, 2)])
 def test_attention_backward_one_pass_equals_two_kernels(mode, S, L, H, vtx_opts):

@@ -45,7 +45,7 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "attn_valu") == 0) { o.attn_valu = atoi(value) != 0; return VTX_OK; }
   if (strcmp(name, "attn_hw_fwd") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.attn_hw_fwd = g; return VTX_OK; }
   if (strcmp(name, "attn_hw_bwd") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.attn_hw_bwd = g; return VTX_OK; }
-  if (strcmp(name, "attn_fused") == 0) { o.attn_fused = atoi(value) != 0; return VTX_OK; }
+  if (strcmp(name, "attn_fused") == 0) { const int v = atoi(value); o.attn_fused = v < 0 ? 0 : v > 2 ? 2 : v; return VTX_OK; }
   if (strcmp(name, "attn_dkv") == 0) { const int g = atoi(value); if (g < 0 || g > 4) return VTX_EINVAL; o.attn_dkv = g; return VTX_OK; }
   if (strcmp(name, "pp_grid") == 0) { const int g = atoi(value); if (g < 8 || g > 4096 || g % 8) return VTX_EINVAL; o.pp_grid = g; return VTX_OK; }
   if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }

@@ -802,6 +802,372 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_fused_mfma_kernel(Attn
   }
 }
 
+// ------------------------------------------------------------------- backward: ONE phase, operands streamed (round 4)
+// The one-pass kernel above still computes every score twice (once per phase, in the layout that phase needs), keeps all
+// four operand tiles in LDS (nothing of the next item can be brought in before the current one is done) and showed that its
+// load time, dq phase and dk / dv phase ADD.  This kernel runs ONE phase per (sequence, head):
+//   * worker w (7 waves) owns key tile w for the whole item: K_w, V_w as row fragments in registers (global -> registers, no
+//     LDS tile), dK^T / dV^T accumulators in registers; it walks the query tiles 0 .. 6 exactly like the dk / dv kernel
+//     (S = Q K^T with lanes = keys, P, dS, dV^T += dO^T P, dK^T += Q^T dS: same products, same order -- dk and dv are
+//     bit-identical to the kernels above);
+//   * the dq contribution of the (query tile, key tile) pair needs dS with lanes = queries: the packed bf16 dS tile (2 KB)
+//     goes through the wave's private LDS scratch as [key][query] and comes back through `ds_read_b64_tr_b16` as the B
+//     operand of dQ^T_partial = K_w^T dS^T (K_w^T fragments: 16 registers per item) -- one exp, one score product and one
+//     dP product per score instead of two;
+//   * the seven partial dQ^T tiles of a query tile (fp32, 8 KB each) meet in LDS: barrier, then each of the 8 waves sums
+//     four query rows over the partials in FIXED order 0 .. 6 and stores them as whole 128-byte rows (deterministic; not the
+//     rounding of the MFMA accumulation chain of the dq kernel: dq equals it to fp32 rounding, not bit for bit);
+//   * Q / dO live in LDS as a RING of seven 32-row tiles: query tile i is dead after step i, and wave 7 (the feeder) puts
+//     the NEXT item's tile i there right away -- its Q / dO / O rows were fetched three tiles ahead into registers, delta =
+//     rowsum(dO * O) is computed on the way, lse and delta are double-buffered by item parity.  No operand of the next
+//     item waits for the end of the current one; the workers fetch their next K / V rows under the dk / dv stores.
+// Barriers are `s_waitcnt lgkmcnt(0); s_barrier` (no vmcnt: prefetches and result stores stay in flight across them).
+// LDS: 2 x 28 KB ring + 56 KB partials + 8 x 4 KB per-wave scratch / store staging + 3.5 KB lse / delta = 147.5 KB.
+constexpr int MG_LP = 224;
+constexpr int MG_TILE = 32 * 64;                // elements of one [32][64] bf16 tile
+constexpr int MG_SLOT_BYTES = 32 * 64 * 4;      // one fp32 dQ^T partial
+constexpr int MG_SCR_LD = 36;                   // dS scratch: [32 keys][36] bf16 (72-byte rows: conflict-free 8-byte stores)
+constexpr size_t MG_LDS_BYTES = (size_t)2 * 7 * MG_TILE * 2 + 7 * MG_SLOT_BYTES + 8 * MA_STAGE_ELEMS * 2 + 2 * 2 * MG_LP * 4 + 3 * MG_TILE * 2;
+
+__device__ inline void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef VTX_STREAM_ABLATE
+#define VTX_STREAM_ABLATE 0   // timing experiments only (wrong results): 1 = the feeder fetches nothing after item 0, 2 = no products /
+#endif                        // softmax in the workers, 4 = no dq sums / stores, 8 = no K / V refetch and no dk / dv stores
+
+template <int NT_>
+__global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+                                                                          const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
+                                                                          const float* __restrict__ lse, bf16raw* __restrict__ dqkv,
+                                                                          bf16raw* __restrict__ dqkv_cls, long long* __restrict__ trace) {
+  static_assert(NT_ == 7, "seven 32-row tiles (193 .. 224 tokens): seven workers + the feeder");
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int D = p.H * 64, items = p.S * p.H;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  bf16raw* Qs = reinterpret_cast<bf16raw*>(sm_raw);
+  bf16raw* Os = Qs + NT_ * MG_TILE;                 // dO
+  char* slots = reinterpret_cast<char*>(Os + NT_ * MG_TILE);
+  bf16raw* stg = reinterpret_cast<bf16raw*>(slots + 7 * MG_SLOT_BYTES) + wave * MA_STAGE_ELEMS;
+  float* LD = reinterpret_cast<float*>(slots + 7 * MG_SLOT_BYTES + 8 * MA_STAGE_ELEMS * 2);   // [parity][lse2 | delta][224]
+  const float c2 = p.scale * LOG2E;
+  const int stride = gridDim.x;
+  if (blockIdx.x >= items) return;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // VTX_STREAM_TRACE (variant builds, tools/attn_timeline.py): shader-clock stamps of wave 0 (a worker) and wave 7 (the feeder)
+  // of workgroup 0 for its first four items: trace[((role * 4 + item) * 8 + step) * 8 + point]
+#ifdef VTX_STREAM_TRACE
+  int tr_item = 0;
+#define MG_STAMP(role_, step_, pt_)                                                                        \
+  if (trace && blockIdx.x == 0 && tr_item < 4) {                                                           \
+    long long t_;                                                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+    if (lane == 0) trace[(((role_) * 4 + tr_item) * 8 + (step_)) * 8 + (pt_)] = t_;                        \
+  }
+#else
+#define MG_STAMP(role_, step_, pt_)
+#endif
+#ifndef VTX_STREAM_STAGGER
+#define VTX_STREAM_STAGGER 0
+#endif
+#ifndef VTX_STREAM_STAGGER_SLEEP
+#define VTX_STREAM_STAGGER_SLEEP 60
+#endif
+  if (VTX_STREAM_STAGGER > 0) {
+    for (int k = (int)(blockIdx.x % VTX_STREAM_STAGGER); k > 0; --k) __builtin_amdgcn_s_sleep(VTX_STREAM_STAGGER_SLEEP);
+  }
+
+  // Sum of the seven partials of query tile i: this wave takes query rows 4 * wave .. + 3, a lane one row and four
+  // consecutive columns.  A partial is stored in accumulator order, 16-byte chunk (j, lane) at position
+  // j * 64 + 32 * half + ((q ^ half) ^ 2 j)  (q = lane & 31, half = lane >> 5; chunk j = registers 4 (j & 3) .. + 3 of C tile
+  // j >> 2 = columns d0 = 4 (2 j + half) .. + 3 of query q): both the writers' and the readers' lane groups touch 16 distinct
+  // chunk positions mod 16.
+  const int rq = 4 * wave + (lane >> 4), rc = lane & 15;
+  const unsigned red_off = (unsigned)((((rc >> 1) * 64 + 32 * (rc & 1) + ((rq ^ (rc & 1)) ^ (rc & 14))) * 16));
+  auto reduce_store = [&](int i, int s, int h, const RowLin& li) {
+    const char* sb = slots + red_off;
+    float4 a = *reinterpret_cast<const float4*>(sb);
+#pragma unroll
+    for (int w = 1; w < 7; ++w) {
+      const float4 b = *reinterpret_cast<const float4*>(sb + w * MG_SLOT_BYTES);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    int rqo = rq;                                   // opaque: the seven row addresses of an item are built here, one per step, not
+    asm volatile("" : "+v"(rqo));                   // hoisted to the top of the item and kept (they were spilled: scratch reloads
+    const int qq = i * 32 + rqo;                    // wait for vmcnt(0), i.e. for the store of the step before)
+    if (qq < p.L) {
+      bf16raw* dst = (p.mode == VTX_ATTN_SPACE && qq == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
+                                                           : dqkv + lin_row(li, qq) * p.ld_dqkv + h * 64;
+      union { bf16x4 v; uint2 u; } w4;
+      w4.v[0] = (__bf16)(a.x * p.scale); w4.v[1] = (__bf16)(a.y * p.scale);
+      w4.v[2] = (__bf16)(a.z * p.scale); w4.v[3] = (__bf16)(a.w * p.scale);
+      *reinterpret_cast<uint2*>(dst + 4 * rc) = w4.u;
+    }
+  };
+
+  if (wave == MF_LOADER) {                          // ---------------------------------------------------------------- feeder
+    // Everything the feeder brings in travels HBM -> LDS by LDS-DMA (no registers, any number of requests in flight): the
+    // Q / dO tile of query tile i of the NEXT item goes straight into ring slot i right after A(i), its O tile into one of
+    // three staging tiles, its lse values into the other parity's lse array -- 13 wave-instructions per step, a whole item
+    // ahead of their first reader.  Two steps later (`s_waitcnt vmcnt(13)`: requests retire in issue order, the 13 of the
+    // step in between may still be in flight) the feeder turns dO (ring) and O (staging) into delta = rowsum(dO * O) and
+    // lse into lse * log2(e).  The schedule rolls over the item boundary: tile j = i - 2 (mod 7), so tiles 5 and 6 of an
+    // item are finished during steps 0 and 1 of that item (their first readers are steps 5 and 6).  The requests are inline
+    // asm: hipcc waits `vmcnt(0)` before LDS reads while a DMA it knows of is in flight, which would park the feeder -- and
+    // with it every barrier -- on the requests it has just issued.
+    typedef __attribute__((address_space(3))) char lds_char;
+    bf16raw* stO = reinterpret_cast<bf16raw*>(reinterpret_cast<char*>(LD) + 2 * 2 * MG_LP * 4);      // [3][32][64] bf16
+    const FragOff ffo = make_frag_off(lane);
+    auto dma_tile = [&](const bf16raw* base, long ld, int col0, const RowLin& rl, int t, bf16raw* dst) {
+      const int rl8 = lane >> 3, pc = lane & 7;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = t * 32 + g * 8 + rl8;
+        const int rcl = r < p.L ? r : p.L - 1;      // padded query rows: any finite values (their lse is +huge)
+        const bf16raw* src = base + lin_row(rl, rcl) * ld + col0 + ((pc ^ sw_of(r)) << 3);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(dst + g * 512));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+      }
+    };
+    auto dma_item_tile = [&](int t, int s, int h, const RowLin& li, const RowLin& lo, bf16raw* ost, float* lsd) {
+      dma_tile(qkv, p.ld_qkv, h * 64, li, t, Qs + t * MG_TILE);
+      dma_tile(dout, p.ld_dout, h * 64, lo, t, Os + t * MG_TILE);
+      dma_tile(o, p.ld_out, h * 64, lo, t, ost);
+      const int row = t * 32 + (lane & 31);
+      const float* src = lse + ((long)s * p.H + h) * p.L + (row < p.L ? row : p.L - 1);
+      const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(lsd + t * 32));
+      if (lane < 32) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+    };
+    // delta and scaled lse of query tile t: dO from ring tile t, O from staging tile `ost`, into the arrays of parity `par`
+    auto finish_tile = [&](int t, const bf16raw* ost, int par) {
+      float dl = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dl = frag_dot2(frag_rows_o(Os, t * 32, ks, ffo), frag_rows_o(ost, 0, ks, ffo), dl);
+      dl += __shfl_xor(dl, 32, 64);
+      if (lane < 32) {
+        const int row = t * 32 + lane;
+        float* lp = LD + par * 2 * MG_LP + row;
+        const float raw = *lp;
+        *lp = row < p.L ? raw * LOG2E : 1e30f;
+        lp[MG_LP] = row < p.L ? dl : 0.f;
+      }
+    };
+    int item = blockIdx.x, par = 0;
+    int s = item / p.H, h = item - s * p.H;
+    RowLin li = lin_in(p, s), lo = lin_out(p, s);
+    // item 0: all seven tiles at once; O tiles 0 .. 4 park in the (still unused) partial slots, 5 and 6 in their staging tiles
+    {
+      bf16raw* park = reinterpret_cast<bf16raw*>(slots);
+#pragma unroll
+      for (int t = 0; t < NT_; ++t)
+        dma_item_tile(t, s, h, li, lo, t < 5 ? park + t * MG_TILE : stO + (t % 3) * MG_TILE, LD);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 5; ++t) finish_tile(t, park + t * MG_TILE, 0);
+    }
+    int k3 = 7 % 3;                                 // (7 (n + 1) + i) % 3: staging tile of the request of step i
+    mg_barrier();                                   // P: item 0 is in the ring
+    while (true) {
+      const int next = item + stride;
+      const bool more = next < items;
+      const int sn = more ? next / p.H : s, hn = more ? next - sn * p.H : h;
+      const RowLin lin = lin_in(p, sn), lon = lin_out(p, sn);
+#pragma unroll
+      for (int i = 0; i < NT_; ++i) {
+        MG_STAMP(1, i, 0)
+        mg_barrier();                               // B(i): nobody reads ring tile i any more
+        MG_STAMP(1, i, 1)
+        mg_barrier();                               // A(i): the partials of query tile i are in LDS
+        MG_STAMP(1, i, 2)
+        if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i, s, h, li);
+        MG_STAMP(1, i, 3)
+        if (!(VTX_STREAM_ABLATE & 1)) {
+          const int kf2 = k3 == 2 ? 0 : k3 + 1;     // (k3 - 2) mod 3: the staging tile of the request two steps ago
+          if (i < 2 || more) {
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            MG_STAMP(1, i, 4)
+            finish_tile(i < 2 ? i + 5 : i - 2, stO + kf2 * MG_TILE, i < 2 ? par : par ^ 1);
+          }
+          MG_STAMP(1, i, 5)
+          if (more) dma_item_tile(i, sn, hn, lin, lon, stO + k3 * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
+          MG_STAMP(1, i, 6)
+        }
+        k3 = k3 == 2 ? 0 : k3 + 1;
+      }
+      if (!more) break;
+      item = next; s = sn; h = hn; li = lin; lo = lon; par ^= 1;
+#ifdef VTX_STREAM_TRACE
+      ++tr_item;
+#endif
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------------------ workers
+  FragOff fo = make_frag_off(lane);
+  int item = blockIdx.x, par = 0;
+  int s = item / p.H, h = item - s * p.H;
+  RowLin li = lin_in(p, s);
+  const int key = wave * 32 + (lane & 31);
+  bf16x8 kf[4], vf[4];
+  load_row_frags(kf, qkv, p.ld_qkv, D + h * 64, li, key, p.L, lane);
+  load_row_frags(vf, qkv, p.ld_qkv, 2 * D + h * 64, li, key, p.L, lane);
+  const bool ragged_wave = wave == NT_ - 1 && (p.L & 31) != 0;
+  // dS scratch addresses (bytes from the wave's staging tile): stores [key][query], 8 bytes = 4 queries; transpose reads
+  char* scr = reinterpret_cast<char*>(stg);
+  const unsigned scr_w = (unsigned)((lane & 31) * (MG_SCR_LD * 2) + 8 * (lane >> 5));
+  const unsigned scr_r = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * (MG_SCR_LD * 2) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+  const unsigned slot_w = (unsigned)((((lane & 31) ^ (lane >> 5)) + 32 * (lane >> 5)) * 16);
+  char* my_slot = slots + wave * MG_SLOT_BYTES;
+  auto scores = [&](int qt, f32x16& st, f32x16& dp) {
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, 0, fo), kf[0], zero, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, 0, fo), vf[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, ks, fo), kf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, ks, fo), vf[ks], dp, 0, 0, 0);
+    }
+  };
+  // (the first item's K / V fragments are complete before the loop is entered: the loop header then needs no wait for them on
+  // either path -- a wait there would, on the back edge, drain the dk / dv stores of the item before)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+  mg_barrier();                                     // P
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.rows[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.cols[i >> 1][i & 1]));
+    MG_STAMP(0, 7, 0)
+    // K_w^T fragments (A operand of dQ^T = K^T dS^T) through the private staging tile
+    put_tile(stg, kf, lane);
+    wave_lds_sync();
+    bf16x8 ktf[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) ktf[s2][n2] = frag_cols_o(stg, 16 * s2, n2, fo);
+    wave_lds_sync();
+    const float* Lc = LD + par * 2 * MG_LP;
+    const float* Dc = Lc + MG_LP;
+    const int next = item + stride;
+    const bool more = next < items;
+    const int nx = more ? next : item;              // last item: the prefetch re-reads the current rows (unused)
+    f32x16 dk[2], dv[2];
+    zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+    f32x16 st = zero, dp = zero;
+    if (!(VTX_STREAM_ABLATE & 2)) scores(0, st, dp);
+    MG_STAMP(0, 7, 1)
+#pragma unroll
+    for (int i = 0; i < NT_; ++i) {
+      MG_STAMP(0, i, 0)
+      f32x16 pq[2] = {zero, zero};
+      if (!(VTX_STREAM_ABLATE & 2)) {
+      float pr[16], ds[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qrow = i * 32 + 8 * g + 4 * (lane >> 5);
+        const float4 l4 = *reinterpret_cast<const float4*>(Lc + qrow);
+        const float4 d4 = *reinterpret_cast<const float4*>(Dc + qrow);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lv[j]));
+          pr[r] = e;
+          ds[r] = e * (dp[r] - dvv[j]);              // the softmax scale is applied once, at the stores
+        }
+      }
+      bf16x8 pb[2], db[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) { pb[s2] = pack8(pr + 8 * s2); db[s2] = pack8(ds + 8 * s2); }
+      MG_STAMP(0, i, 1)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, i * 32 + 16 * s2, n2, fo), pb[s2], dv[n2], 0, 0, 0);
+          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, i * 32 + 16 * s2, n2, fo), db[s2], dk[n2], 0, 0, 0);
+        }
+      // dS^T: padded keys (only the last key tile has any) must not reach dq -- their dk / dv columns are never stored,
+      // but a dq row sums over all keys
+      if (ragged_wave && key >= p.L) { db[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; db[1] = db[0]; }
+      {
+        union { bf16x8 v; uint2 u[2]; } x0, x1;
+        x0.v = db[0]; x1.v = db[1];
+        *reinterpret_cast<uint2*>(scr + scr_w) = x0.u[0];          // queries  0 ..  3 (+ 4 half)
+        *reinterpret_cast<uint2*>(scr + scr_w + 16) = x0.u[1];     //          8 .. 11
+        *reinterpret_cast<uint2*>(scr + scr_w + 32) = x1.u[0];     //         16 .. 19
+        *reinterpret_cast<uint2*>(scr + scr_w + 48) = x1.u[1];     //         24 .. 27
+      }
+      wave_lds_sync();
+      MG_STAMP(0, i, 2)
+      bf16x8 dbt[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        union { bf16x8 v; s16x4 hh[2]; } u;
+        u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(scr + scr_r + s2 * 16 * MG_SCR_LD * 2));
+        u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(scr + scr_r + s2 * 16 * MG_SCR_LD * 2 + 8 * MG_SCR_LD * 2));
+        dbt[s2] = u.v;
+      }
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        pq[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][n2], dbt[0], zero, 0, 0, 0);
+        pq[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][n2], dbt[1], pq[n2], 0, 0, 0);
+      }
+      }
+      MG_STAMP(0, i, 3)
+      mg_barrier();                                 // B(i): the partials of query tile i - 1 have been read
+      MG_STAMP(0, i, 4)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float4 v;
+        v.x = pq[j >> 2][4 * (j & 3)]; v.y = pq[j >> 2][4 * (j & 3) + 1];
+        v.z = pq[j >> 2][4 * (j & 3) + 2]; v.w = pq[j >> 2][4 * (j & 3) + 3];
+        *reinterpret_cast<float4*>(my_slot + j * 1024 + (slot_w ^ (unsigned)(32 * j))) = v;
+      }
+      MG_STAMP(0, i, 5)
+      mg_barrier();                                 // A(i)
+      MG_STAMP(0, i, 6)
+      // the next query tile's score products go to the matrix pipe first, the sums and the store of this one run beside them
+      // (issued BEFORE the hand-over they cost 32 more live registers than two waves per SIMD have: spills in the step loop)
+      if (i + 1 < NT_ && !(VTX_STREAM_ABLATE & 2)) scores(i + 1, st, dp);
+      if (i + 1 == NT_ - 1 && !(VTX_STREAM_ABLATE & 8)) {
+        // K_w / V_w have had their last use: the next item's rows are requested now, a whole step ahead of their first use
+        int nxo = nx;                               // opaque: the addresses are built here, not at the top of the item (spills)
+        asm volatile("" : "+s"(nxo));
+        const int sn = nxo / p.H, hn = nxo - sn * p.H;
+        const RowLin lin = lin_in(p, sn);
+        load_row_frags(kf, qkv, p.ld_qkv, D + hn * 64, lin, key, p.L, lane);
+        load_row_frags(vf, qkv, p.ld_qkv, 2 * D + hn * 64, lin, key, p.L, lane);
+      }
+      if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i, s, h, li);
+      MG_STAMP(0, i, 7)
+    }
+    // The next item's K / V fragments are waited for HERE (requested a step ago; the counted wait the compiler derives only
+    // covers what is older than the two dq stores issued since), in front of the dk / dv stores: requests retire in order,
+    // so a wait at the top of the next item would also drain these eight stores.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+    MG_STAMP(0, 7, 2)
+    if (!(VTX_STREAM_ABLATE & 8)) {
+      auto base_of = [&](int r) -> bf16raw* {
+        const int kk = wave * 32 + r;
+        if (kk >= p.L) return nullptr;
+        return (p.mode == VTX_ATTN_SPACE && kk == 0) ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + lin_row(li, kk) * p.ld_dqkv;
+      };
+      store_rows_T(stg, dk, p.scale, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + D + h * 64 : nullptr; });
+      store_rows_T(stg, dv, 1.0f, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + 2 * D + h * 64 : nullptr; });
+    }
+    MG_STAMP(0, 7, 3)
+    if (!more) break;
+    item = next; s = item / p.H; h = item - s * p.H; li = lin_in(p, s); par ^= 1;
+#ifdef VTX_STREAM_TRACE
+    ++tr_item;
+#endif
+  }
+}
+
 // =====================================================================================
 // Short sequences (L <= 32, contiguous rows): temporal attention of the divided block
 // (L = T = 8) and ViViT's temporal encoder (L = 9).  G = 32/L sequences are packed into one
@@ -1107,9 +1473,20 @@ static int attn_bwd_fused_launch_t(const AttnP& p, const void* qkv, const void* 
   return check_launch("attn_bwd_fused_mfma");
 }
 
+static int attn_bwd_stream_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                                  void* dqkv_cls, hipStream_t st) {
+  allow_lds<attn_bwd_stream_mfma_kernel<7>>(MG_LDS_BYTES);
+  const int items = p.S * p.H, cus = device_cus();          // one workgroup per CU, persistent over the items (heads fastest)
+  hipLaunchKernelGGL(attn_bwd_stream_mfma_kernel<7>, dim3(items < cus ? items : cus), dim3(MF_THREADS), MG_LDS_BYTES, st, p,
+                     (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv, (bf16raw*)dqkv_cls,
+                     reinterpret_cast<long long*>(options().pp_trace));
+  return check_launch("attn_bwd_stream_mfma");
+}
+
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
   const int nt = (p.L + 31) >> 5;
+  if (options().attn_fused >= 2 && nt == 7) return attn_bwd_stream_launch(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
   if (options().attn_fused && nt <= 7) {           // one pass over HBM: all four operand tiles fit the LDS of one workgroup
     if (nt == 7) return attn_bwd_fused_launch_t<7>(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
     return attn_bwd_fused_launch_t<0>(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
