@@ -830,6 +830,79 @@ constexpr int MG_SCR_LD = 36;                   // dS scratch: [32 keys][36] bf1
 constexpr size_t MG_LDS_BYTES = (size_t)2 * 7 * MG_TILE * 2 + 7 * MG_SLOT_BYTES + 8 * MA_STAGE_ELEMS * 2 + 2 * 2 * MG_LP * 4 + 3 * MG_TILE * 2;
 
 __device__ inline void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// n / d for 0 <= n < 2^24 with inv = 1.0f / d (an integer division is ~40 vector instructions; the item -> (sequence, head) and
+// sequence -> (clip, frame) splits are on the path between two items)
+__device__ inline int mg_div(int n, int d, float inv) {
+  int q = (int)((float)n * inv);
+  const int r = n - q * d;
+  q += r >= d ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
+__device__ inline RowLin mg_lin_in(const AttnP& p, int s, float invT) {
+  RowLin r;
+  if (p.mode == VTX_ATTN_CONTIG) { r.base = (long)s * p.L; r.stride = 1; r.row0 = r.base; return r; }
+  const int b = mg_div(s, p.T, invT), t = s - b * p.T;
+  r.row0 = (long)b * (1 + (long)p.P * p.T);
+  r.stride = p.T;
+  r.base = r.row0 + 1 + t - r.stride;
+  return r;
+}
+__device__ inline RowLin mg_lin_out(const AttnP& p, int s, float invT) {
+  RowLin r;
+  if (p.mode == VTX_ATTN_CONTIG) { r.base = (long)s * p.L; r.stride = 1; r.row0 = r.base; return r; }
+  const int b = mg_div(s, p.T, invT), t = s - b * p.T;
+  r.row0 = (long)p.B * p.P * p.T + s;
+  r.stride = p.T;
+  r.base = (long)b * p.P * p.T + t - r.stride;
+  return r;
+}
+// One [32][64] bf16 tile, rows row0 .. row0 + 31 of a sequence, fetched as whole 128-byte rows: lane -> row 8 g + lane / 8,
+// 16-byte chunk lane % 8 (8 rows = 8 full lines per wave-instruction; the row-per-lane fragment pattern of load_row_frags
+// touches 32 lines for 32 bytes each, and the vector memory pipeline works line by line: 8 such loads cost ~3000 cycles).
+// Rows are linear in the token index except the sequence's row 0; rows beyond nvalid read row nvalid - 1.
+__device__ inline void mg_load_tile_raw(u32x4 (&raw)[4], const bf16raw* base, long ld, int col0, const RowLin& rl, int row0, int nvalid,
+                                        int lane) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = row0 + g * 8 + (lane >> 3);
+    const int rc = r < nvalid ? r : nvalid - 1;
+    raw[g] = *reinterpret_cast<const u32x4*>(base + lin_row(rl, rc) * ld + col0 + (lane & 7) * 8);
+  }
+}
+__device__ inline void mg_raw_to_tile(bf16raw* tile, const u32x4 (&raw)[4], int lane) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = g * 8 + (lane >> 3);
+    *reinterpret_cast<u32x4*>(tile + r * 64 + (((lane & 7) ^ sw_of(r)) << 3)) = raw[g];
+  }
+}
+// store_rows_T with the destination rows in closed form: tile row r = 8 i + lane / 8 goes to p_lin + i * step8 (elements), tile
+// row 0 to p_row0 (the sequence's row 0 is not on the line), rows >= nrows are not stored.  (The general form calls a row
+// function per store: ~20 vector instructions of 64-bit arithmetic each.)
+__device__ inline void mg_store_rows_lin(bf16raw* stg, const f32x16 (&acc)[2], float mul, int lane, bf16raw* p_lin, long step8,
+                                         bf16raw* p_row0, int nrows) {
+  const int row = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = nt * 32 + 8 * g + 4 * (lane >> 5);
+      union { bf16x4 v; uint2 u; } w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w.v[j] = (__bf16)(acc[nt][4 * g + j] * mul);
+      *reinterpret_cast<uint2*>(stg + sw_off(row, col)) = w.u;
+    }
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = i * 8 + (lane >> 3), c = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(stg + r * 64 + ((c ^ sw_of(r)) << 3));
+    bf16raw* dst = (i == 0 && r == 0) ? p_row0 : p_lin + i * step8;
+    if (r < nrows) *reinterpret_cast<uint4*>(dst + c * 8) = v;
+  }
+  wave_lds_sync();
+}
 #ifndef VTX_STREAM_ABLATE
 #define VTX_STREAM_ABLATE 0   // timing experiments only (wrong results): 1 = the feeder fetches nothing after item 0, 2 = no products /
 #endif                        // softmax in the workers, 4 = no dq sums / stores, 8 = no K / V refetch and no dk / dv stores
@@ -882,7 +955,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
   // chunk positions mod 16.
   const int rq = 4 * wave + (lane >> 4), rc = lane & 15;
   const unsigned red_off = (unsigned)((((rc >> 1) * 64 + 32 * (rc & 1) + ((rq ^ (rc & 1)) ^ (rc & 14))) * 16));
-  auto reduce_store = [&](int i, int s, int h, const RowLin& li) {
+  // dq rows of this lane: query row i * 32 + rq of the item -> dq_lin + i * dq_step (elements), row 0 of the sequence -> dq_row0
+  // (set per item by set_dq_rows)
+  bf16raw* dq_lin = nullptr;
+  bf16raw* dq_row0 = nullptr;
+  long dq_step = 0;
+  auto set_dq_rows = [&](int s, int h, const RowLin& li) {
+    dq_lin = dqkv + (li.base + (long)rq * li.stride) * p.ld_dqkv + h * 64 + 4 * rc;
+    dq_row0 = (p.mode == VTX_ATTN_SPACE ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + li.row0 * p.ld_dqkv) + h * 64 + 4 * rc;
+    dq_step = 32 * li.stride * p.ld_dqkv;
+  };
+  auto reduce_store = [&](int i) {
     const char* sb = slots + red_off;
     float4 a = *reinterpret_cast<const float4*>(sb);
 #pragma unroll
@@ -890,18 +973,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       const float4 b = *reinterpret_cast<const float4*>(sb + w * MG_SLOT_BYTES);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    int rqo = rq;                                   // opaque: the seven row addresses of an item are built here, one per step, not
-    asm volatile("" : "+v"(rqo));                   // hoisted to the top of the item and kept (they were spilled: scratch reloads
-    const int qq = i * 32 + rqo;                    // wait for vmcnt(0), i.e. for the store of the step before)
-    if (qq < p.L) {
-      bf16raw* dst = (p.mode == VTX_ATTN_SPACE && qq == 0) ? dqkv_cls + (long)s * p.ld_dqkv + h * 64
-                                                           : dqkv + lin_row(li, qq) * p.ld_dqkv + h * 64;
+    bf16raw* dst = (i == 0 && rq == 0) ? dq_row0 : dq_lin + i * dq_step;
+    if (i * 32 + rq < p.L) {
       union { bf16x4 v; uint2 u; } w4;
       w4.v[0] = (__bf16)(a.x * p.scale); w4.v[1] = (__bf16)(a.y * p.scale);
       w4.v[2] = (__bf16)(a.z * p.scale); w4.v[3] = (__bf16)(a.w * p.scale);
-      *reinterpret_cast<uint2*>(dst + 4 * rc) = w4.u;
+      *reinterpret_cast<uint2*>(dst) = w4.u;
     }
   };
+  const float invH = 1.0f / (float)p.H, invT = p.mode == VTX_ATTN_SPACE ? 1.0f / (float)p.T : 1.0f;
 
   if (wave == MF_LOADER) {                          // ---------------------------------------------------------------- feeder
     // Everything the feeder brings in travels HBM -> LDS by LDS-DMA (no registers, any number of requests in flight): the
@@ -916,23 +996,46 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
     typedef __attribute__((address_space(3))) char lds_char;
     bf16raw* stO = reinterpret_cast<bf16raw*>(reinterpret_cast<char*>(LD) + 2 * 2 * MG_LP * 4);      // [3][32][64] bf16
     const FragOff ffo = make_frag_off(lane);
-    auto dma_tile = [&](const bf16raw* base, long ld, int col0, const RowLin& rl, int t, bf16raw* dst) {
-      const int rl8 = lane >> 3, pc = lane & 7;
+    // Row addresses in closed form (a 64-bit multiply-add per request otherwise: the 13 requests of a step took 1600 cycles):
+    // row r = 8 G + lane / 8 of a sequence sits at p1 + G * inc8 except row 0 (p0) and the clamped rows beyond L - 1 (plast);
+    // the chunk swizzle of the destination row only depends on the parity of G.
+    struct Src { const bf16raw* p1; const bf16raw* p0; const bf16raw* plast; long inc8; };
+    const int rl8 = lane >> 3, pc = lane & 7;
+    const int swz[2] = {(pc ^ sw_of(rl8)) << 3, (pc ^ sw_of(8 + rl8)) << 3};
+    auto make_src = [&](const bf16raw* base, long ld, int col0, const RowLin& rl) {
+      Src x;
+      x.p1 = base + (rl.base + (long)rl8 * rl.stride) * ld + col0;
+      x.p0 = base + rl.row0 * ld + col0;
+      x.plast = base + lin_row(rl, p.L - 1) * ld + col0;
+      x.inc8 = 8 * rl.stride * ld;
+      return x;
+    };
+    auto dma_tile = [&](const Src& x, int t, bf16raw* dst) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int r = t * 32 + g * 8 + rl8;
-        const int rcl = r < p.L ? r : p.L - 1;      // padded query rows: any finite values (their lse is +huge)
-        const bf16raw* src = base + lin_row(rl, rcl) * ld + col0 + ((pc ^ sw_of(r)) << 3);
+        const int G = 4 * t + g;
+        const bf16raw* src = x.p1 + G * x.inc8;
+        if (G == 0) src = rl8 == 0 ? x.p0 : src;
+        if (t == NT_ - 1) src = G * 8 + rl8 >= p.L ? x.plast : src;      // padded query rows: any finite values (their lse is +huge)
+        src += swz[g & 1];
         const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(dst + g * 512));
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
       }
     };
-    auto dma_item_tile = [&](int t, int s, int h, const RowLin& li, const RowLin& lo, bf16raw* ost, float* lsd) {
-      dma_tile(qkv, p.ld_qkv, h * 64, li, t, Qs + t * MG_TILE);
-      dma_tile(dout, p.ld_dout, h * 64, lo, t, Os + t * MG_TILE);
-      dma_tile(o, p.ld_out, h * 64, lo, t, ost);
+    Src sq, sd, so;
+    const float* slse = nullptr;                    // lse row of the item the requests are for
+    auto set_item = [&](int s, int h, const RowLin& li, const RowLin& lo) {
+      sq = make_src(qkv, p.ld_qkv, h * 64, li);
+      sd = make_src(dout, p.ld_dout, h * 64, lo);
+      so = make_src(o, p.ld_out, h * 64, lo);
+      slse = lse + ((long)s * p.H + h) * p.L;
+    };
+    auto dma_item_tile = [&](int t, bf16raw* ost, float* lsd) {
+      dma_tile(sq, t, Qs + t * MG_TILE);
+      dma_tile(sd, t, Os + t * MG_TILE);
+      dma_tile(so, t, ost);
       const int row = t * 32 + (lane & 31);
-      const float* src = lse + ((long)s * p.H + h) * p.L + (row < p.L ? row : p.L - 1);
+      const float* src = slse + (row < p.L ? row : p.L - 1);
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(lsd + t * 32));
       if (lane < 32) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     };
@@ -951,14 +1054,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       }
     };
     int item = blockIdx.x, par = 0;
-    int s = item / p.H, h = item - s * p.H;
-    RowLin li = lin_in(p, s), lo = lin_out(p, s);
+    int s = mg_div(item, p.H, invH), h = item - s * p.H;
+    RowLin li = mg_lin_in(p, s, invT), lo = mg_lin_out(p, s, invT);
+    set_dq_rows(s, h, li);
     // item 0: all seven tiles at once; O tiles 0 .. 4 park in the (still unused) partial slots, 5 and 6 in their staging tiles
     {
       bf16raw* park = reinterpret_cast<bf16raw*>(slots);
+      set_item(s, h, li, lo);
 #pragma unroll
-      for (int t = 0; t < NT_; ++t)
-        dma_item_tile(t, s, h, li, lo, t < 5 ? park + t * MG_TILE : stO + (t % 3) * MG_TILE, LD);
+      for (int t = 0; t < NT_; ++t) dma_item_tile(t, t < 5 ? park + t * MG_TILE : stO + (t % 3) * MG_TILE, LD);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int t = 0; t < 5; ++t) finish_tile(t, park + t * MG_TILE, 0);
@@ -968,8 +1072,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
     while (true) {
       const int next = item + stride;
       const bool more = next < items;
-      const int sn = more ? next / p.H : s, hn = more ? next - sn * p.H : h;
-      const RowLin lin = lin_in(p, sn), lon = lin_out(p, sn);
+      const int sn = more ? mg_div(next, p.H, invH) : s, hn = more ? next - sn * p.H : h;
+      const RowLin lin = mg_lin_in(p, sn, invT), lon = mg_lin_out(p, sn, invT);
+      if (more) set_item(sn, hn, lin, lon);
 #pragma unroll
       for (int i = 0; i < NT_; ++i) {
         MG_STAMP(1, i, 0)
@@ -977,7 +1082,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
         MG_STAMP(1, i, 1)
         mg_barrier();                               // A(i): the partials of query tile i are in LDS
         MG_STAMP(1, i, 2)
-        if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i, s, h, li);
+        if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i);
         MG_STAMP(1, i, 3)
         if (!(VTX_STREAM_ABLATE & 1)) {
           const int kf2 = k3 == 2 ? 0 : k3 + 1;     // (k3 - 2) mod 3: the staging tile of the request two steps ago
@@ -987,13 +1092,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
             finish_tile(i < 2 ? i + 5 : i - 2, stO + kf2 * MG_TILE, i < 2 ? par : par ^ 1);
           }
           MG_STAMP(1, i, 5)
-          if (more) dma_item_tile(i, sn, hn, lin, lon, stO + k3 * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
+          if (more) dma_item_tile(i, stO + k3 * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
           MG_STAMP(1, i, 6)
         }
         k3 = k3 == 2 ? 0 : k3 + 1;
       }
       if (!more) break;
       item = next; s = sn; h = hn; li = lin; lo = lon; par ^= 1;
+      set_dq_rows(s, h, li);
 #ifdef VTX_STREAM_TRACE
       ++tr_item;
 #endif
@@ -1004,12 +1110,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
   // ------------------------------------------------------------------------------------------------------------ workers
   FragOff fo = make_frag_off(lane);
   int item = blockIdx.x, par = 0;
-  int s = item / p.H, h = item - s * p.H;
-  RowLin li = lin_in(p, s);
+  int s = mg_div(item, p.H, invH), h = item - s * p.H;
+  RowLin li = mg_lin_in(p, s, invT);
   const int key = wave * 32 + (lane & 31);
+  // K_w / V_w arrive as whole rows (kr / vr: row 8 g + lane / 8, chunk lane % 8) and become fragments through the staging tile
+  u32x4 kr[4], vr[4];
+  mg_load_tile_raw(kr, qkv, p.ld_qkv, D + h * 64, li, wave * 32, p.L, lane);
+  mg_load_tile_raw(vr, qkv, p.ld_qkv, 2 * D + h * 64, li, wave * 32, p.L, lane);
   bf16x8 kf[4], vf[4];
-  load_row_frags(kf, qkv, p.ld_qkv, D + h * 64, li, key, p.L, lane);
-  load_row_frags(vf, qkv, p.ld_qkv, 2 * D + h * 64, li, key, p.L, lane);
   const bool ragged_wave = wave == NT_ - 1 && (p.L & 31) != 0;
   // dS scratch addresses (bytes from the wave's staging tile): stores [key][query], 8 bytes = 4 queries; transpose reads
   char* scr = reinterpret_cast<char*>(stg);
@@ -1029,7 +1137,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
   // (the first item's K / V fragments are complete before the loop is entered: the loop header then needs no wait for them on
   // either path -- a wait there would, on the back edge, drain the dk / dv stores of the item before)
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kr[ks]), "+v"(vr[ks]));
   mg_barrier();                                     // P
   while (true) {
 #pragma unroll
@@ -1037,14 +1145,23 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.cols[i >> 1][i & 1]));
     MG_STAMP(0, 7, 0)
-    // K_w^T fragments (A operand of dQ^T = K^T dS^T) through the private staging tile
-    put_tile(stg, kf, lane);
+    // K_w: row fragments (B operand of S = Q K^T) and transposed fragments (A operand of dQ^T = K^T dS^T), V_w: row fragments,
+    // through the private staging tile
+    set_dq_rows(s, h, li);
+    mg_raw_to_tile(stg, kr, lane);
     wave_lds_sync();
     bf16x8 ktf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_rows_o(stg, 0, ks, fo);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2) ktf[s2][n2] = frag_cols_o(stg, 16 * s2, n2, fo);
+    wave_lds_sync();
+    mg_raw_to_tile(stg, vr, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = frag_rows_o(stg, 0, ks, fo);
     wave_lds_sync();
     const float* Lc = LD + par * 2 * MG_LP;
     const float* Dc = Lc + MG_LP;
@@ -1076,28 +1193,31 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
           ds[r] = e * (dp[r] - dvv[j]);              // the softmax scale is applied once, at the stores
         }
       }
+      // order: dS on its way through the scratch first, the dV products while it travels, then the dQ partial (the hand-over
+      // below waits for it), the dK products last (their accumulators are not read before the next step)
       bf16x8 pb[2], db[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) { pb[s2] = pack8(pr + 8 * s2); db[s2] = pack8(ds + 8 * s2); }
-      MG_STAMP(0, i, 1)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, i * 32 + 16 * s2, n2, fo), pb[s2], dv[n2], 0, 0, 0);
-          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, i * 32 + 16 * s2, n2, fo), db[s2], dk[n2], 0, 0, 0);
-        }
-      // dS^T: padded keys (only the last key tile has any) must not reach dq -- their dk / dv columns are never stored,
-      // but a dq row sums over all keys
-      if (ragged_wave && key >= p.L) { db[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; db[1] = db[0]; }
+      for (int s2 = 0; s2 < 2; ++s2) db[s2] = pack8(ds + 8 * s2);
       {
+        // dS^T: padded keys (only the last key tile has any) must not reach dq -- their dk / dv columns are never stored,
+        // but a dq row sums over all keys
+        bf16x8 dm[2] = {db[0], db[1]};
+        if (ragged_wave && key >= p.L) { dm[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; dm[1] = dm[0]; }
         union { bf16x8 v; uint2 u[2]; } x0, x1;
-        x0.v = db[0]; x1.v = db[1];
+        x0.v = dm[0]; x1.v = dm[1];
         *reinterpret_cast<uint2*>(scr + scr_w) = x0.u[0];          // queries  0 ..  3 (+ 4 half)
         *reinterpret_cast<uint2*>(scr + scr_w + 16) = x0.u[1];     //          8 .. 11
         *reinterpret_cast<uint2*>(scr + scr_w + 32) = x1.u[0];     //         16 .. 19
         *reinterpret_cast<uint2*>(scr + scr_w + 48) = x1.u[1];     //         24 .. 27
       }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) pb[s2] = pack8(pr + 8 * s2);
+      MG_STAMP(0, i, 1)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, i * 32 + 16 * s2, n2, fo), pb[s2], dv[n2], 0, 0, 0);
       wave_lds_sync();
       MG_STAMP(0, i, 2)
       bf16x8 dbt[2];
@@ -1115,6 +1235,11 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
         pq[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][n2], dbt[0], zero, 0, 0, 0);
         pq[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][n2], dbt[1], pq[n2], 0, 0, 0);
       }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, i * 32 + 16 * s2, n2, fo), db[s2], dk[n2], 0, 0, 0);
       }
       MG_STAMP(0, i, 3)
       mg_barrier();                                 // B(i): the partials of query tile i - 1 have been read
@@ -1136,32 +1261,34 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
         // K_w / V_w have had their last use: the next item's rows are requested now, a whole step ahead of their first use
         int nxo = nx;                               // opaque: the addresses are built here, not at the top of the item (spills)
         asm volatile("" : "+s"(nxo));
-        const int sn = nxo / p.H, hn = nxo - sn * p.H;
-        const RowLin lin = lin_in(p, sn);
-        load_row_frags(kf, qkv, p.ld_qkv, D + hn * 64, lin, key, p.L, lane);
-        load_row_frags(vf, qkv, p.ld_qkv, 2 * D + hn * 64, lin, key, p.L, lane);
+        const int sn = mg_div(nxo, p.H, invH), hn = nxo - sn * p.H;
+        const RowLin lin = mg_lin_in(p, sn, invT);
+        mg_load_tile_raw(kr, qkv, p.ld_qkv, D + hn * 64, lin, wave * 32, p.L, lane);
+        mg_load_tile_raw(vr, qkv, p.ld_qkv, 2 * D + hn * 64, lin, wave * 32, p.L, lane);
       }
-      if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i, s, h, li);
+      if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i);
       MG_STAMP(0, i, 7)
     }
     // The next item's K / V fragments are waited for HERE (requested a step ago; the counted wait the compiler derives only
     // covers what is older than the two dq stores issued since), in front of the dk / dv stores: requests retire in order,
     // so a wait at the top of the next item would also drain these eight stores.
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kr[ks]), "+v"(vr[ks]));
     MG_STAMP(0, 7, 2)
     if (!(VTX_STREAM_ABLATE & 8)) {
-      auto base_of = [&](int r) -> bf16raw* {
-        const int kk = wave * 32 + r;
-        if (kk >= p.L) return nullptr;
-        return (p.mode == VTX_ATTN_SPACE && kk == 0) ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + lin_row(li, kk) * p.ld_dqkv;
-      };
-      store_rows_T(stg, dk, p.scale, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + D + h * 64 : nullptr; });
-      store_rows_T(stg, dv, 1.0f, lane, [&](int r) -> bf16raw* { bf16raw* b = base_of(r); return b ? b + 2 * D + h * 64 : nullptr; });
+      // tile row r = key wave * 32 + r: linear in r except the sequence's row 0 (wave 0, r = 0)
+      const long krow = wave * 32 + (lane >> 3);
+      bf16raw* p_lin = dqkv + (li.base + krow * li.stride) * p.ld_dqkv + D + h * 64;
+      bf16raw* p_row0 = wave == 0 ? (p.mode == VTX_ATTN_SPACE ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + li.row0 * p.ld_dqkv) + D + h * 64
+                                  : p_lin;
+      const long step8 = 8 * li.stride * p.ld_dqkv;
+      const int nrows = p.L - wave * 32;
+      mg_store_rows_lin(stg, dk, p.scale, lane, p_lin, step8, p_row0, nrows);
+      mg_store_rows_lin(stg, dv, 1.0f, lane, p_lin + D, step8, p_row0 + D, nrows);
     }
     MG_STAMP(0, 7, 3)
     if (!more) break;
-    item = next; s = item / p.H; h = item - s * p.H; li = lin_in(p, s); par ^= 1;
+    item = next; s = mg_div(item, p.H, invH); h = item - s * p.H; li = mg_lin_in(p, s, invT); par ^= 1;
 #ifdef VTX_STREAM_TRACE
     ++tr_item;
 #endif
