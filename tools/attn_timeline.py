@@ -41,18 +41,19 @@ vtx.set_option('pp_trace', '0')
 t = trace.cpu().view(2, 4, 8, 8).numpy()
 if not t.any():
     sys.exit('no stamps: load a VTX_STREAM_TRACE build (VTX_LIB=...)')
-wn = ['top', 'packed', 'dS in LDS', 'pq issued', 'B passed', 'slot written', 'A passed', 'scores+reduce']
+wn = ['top', 'packed + dS written', 'dv / dk issued', 'next scores issued', 'barrier passed']
 print('worker (wave 0): cycles from the previous point; columns = steps 0..6')
 for it in (1, 2, 3):
-    print(f' item {it}: item top (K^T frags + scores 0) {t[0, it, 7, 1] - t[0, it, 7, 0]}; previous item end: kv wait '
-          f'{t[0, it - 1, 7, 2] - t[0, it - 1, 6, 7]}, dk/dv stores {t[0, it - 1, 7, 3] - t[0, it - 1, 7, 2]}, '
+    print(f' item {it}: item top (K / V fragments + scores 0) {t[0, it, 7, 1] - t[0, it, 7, 0]}; previous item end: kv wait '
+          f'{t[0, it - 1, 7, 2] - t[0, it - 1, 6, 4]}, dk/dv stores {t[0, it - 1, 7, 3] - t[0, it - 1, 7, 2]}, '
           f'to this top {t[0, it, 7, 0] - t[0, it - 1, 7, 3]};  whole item {t[0, it, 7, 3] - t[0, it - 1, 7, 3]} cycles')
-    for pt in range(1, 8):
-        print(f'   {wn[pt]:14s}', ' '.join(f'{int(t[0, it, i, pt] - t[0, it, i, pt - 1]):6d}' for i in range(7)))
-    print('   step total    ', ' '.join(f'{int(t[0, it, i, 7] - t[0, it, i, 0]):6d}' for i in range(7)))
-fn = ['(arrive)', 'B passed', 'A passed', 'reduce', 'vmcnt(13)', 'finish tile', 'dma issued']
-print('feeder (wave 7)')
+    for pt in range(1, 5):
+        print(f'   {wn[pt]:20s}', ' '.join(f'{int(t[0, it, i, pt] - t[0, it, i, pt - 1]):6d}' for i in range(7)))
+    print('   step total          ', ' '.join(f'{int(t[0, it, i, 4] - t[0, it, i, 0]):6d}' for i in range(7)))
+fn = ['(arrive)', 'barrier passed', 'dq products', 'dq stored', 'vmcnt(13)', 'finish tile', 'dma issued']
+print('wave 7')
 for it in (1, 2):
+    print(f' item {it}: wait at T {t[1, it, 7, 0] - t[1, it - 1, 6, 6]} (from the last request of the item before), K^T fragments {t[1, it, 7, 1] - t[1, it, 7, 0]}')
     for pt in range(1, 7):
-        print(f'   {fn[pt]:14s}', ' '.join(f'{int(t[1, it, i, pt] - t[1, it, i, pt - 1]):6d}' for i in range(7)))
-    print('   idle to next B', ' '.join(f'{int((t[1, it, i + 1, 0] if i < 6 else t[1, it + 1, 0, 0]) - t[1, it, i, 6]):6d}' for i in range(7)))
+        print(f'   {fn[pt]:20s}', ' '.join(f'{int(t[1, it, i, pt] - t[1, it, i, pt - 1]):6d}' for i in range(7)))
+    print('   to next barrier     ', ' '.join(f'{int((t[1, it, i + 1, 0] if i < 6 else t[1, it + 1, 7, 0]) - t[1, it, i, 6]):6d}' for i in range(7)))

@@ -806,28 +806,30 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_fused_mfma_kernel(Attn
 // The one-pass kernel above still computes every score twice (once per phase, in the layout that phase needs), keeps all
 // four operand tiles in LDS (nothing of the next item can be brought in before the current one is done) and showed that its
 // load time, dq phase and dk / dv phase ADD.  This kernel runs ONE phase per (sequence, head):
-//   * worker w (7 waves) owns key tile w for the whole item: K_w, V_w as row fragments in registers (global -> registers, no
-//     LDS tile), dK^T / dV^T accumulators in registers; it walks the query tiles 0 .. 6 exactly like the dk / dv kernel
-//     (S = Q K^T with lanes = keys, P, dS, dV^T += dO^T P, dK^T += Q^T dS: same products, same order -- dk and dv are
-//     bit-identical to the kernels above);
-//   * the dq contribution of the (query tile, key tile) pair needs dS with lanes = queries: the packed bf16 dS tile (2 KB)
-//     goes through the wave's private LDS scratch as [key][query] and comes back through `ds_read_b64_tr_b16` as the B
-//     operand of dQ^T_partial = K_w^T dS^T (K_w^T fragments: 16 registers per item) -- one exp, one score product and one
-//     dP product per score instead of two;
-//   * the seven partial dQ^T tiles of a query tile (fp32, 8 KB each) meet in LDS: barrier, then each of the 8 waves sums
-//     four query rows over the partials in FIXED order 0 .. 6 and stores them as whole 128-byte rows (deterministic; not the
-//     rounding of the MFMA accumulation chain of the dq kernel: dq equals it to fp32 rounding, not bit for bit);
-//   * Q / dO live in LDS as a RING of seven 32-row tiles: query tile i is dead after step i, and wave 7 (the feeder) puts
-//     the NEXT item's tile i there right away -- its Q / dO / O rows were fetched three tiles ahead into registers, delta =
-//     rowsum(dO * O) is computed on the way, lse and delta are double-buffered by item parity.  No operand of the next
-//     item waits for the end of the current one; the workers fetch their next K / V rows under the dk / dv stores.
-// Barriers are `s_waitcnt lgkmcnt(0); s_barrier` (no vmcnt: prefetches and result stores stay in flight across them).
-// LDS: 2 x 28 KB ring + 56 KB partials + 8 x 4 KB per-wave scratch / store staging + 3.5 KB lse / delta = 147.5 KB.
+//   * worker w (waves 0 .. 6) owns key tile w for the whole item: K_w, V_w as row fragments in registers, dK^T / dV^T
+//     accumulators in registers; it walks the query tiles 0 .. 6 exactly like the dk / dv kernel (S = Q K^T with lanes =
+//     keys, P, dS, dV^T += dO^T P, dK^T += Q^T dS: same products, same order -- dk and dv are bit-identical to the kernels
+//     above) -- one exp, one score product and one dP product per score instead of two;
+//   * dq needs dS with lanes = queries and a sum over ALL key tiles.  Each worker drops its packed bf16 dS tile (2 KB, as
+//     [key][query]) into a double-buffered LDS exchange area; after the step's barrier WAVE 7 reads the seven tiles back
+//     through `ds_read_b64_tr_b16` as B operands and runs the whole dQ^T tile of the step, 28 MFMAs against the item's K^T
+//     fragments (112 registers, taken from the workers' staging tiles at the top of the item), accumulating over the key
+//     tiles in the matrix instruction like the dq kernel does (same order), and stores it as whole 128-byte rows.  (The
+//     first version let every worker form its own fp32 partial dQ^T and summed the seven partials through LDS: 56 KB of
+//     LDS writes per step at ~80 B/clk, two barriers per step, 16 registers of K^T fragments per worker.)
+//   * Q / dO live in LDS as a RING of seven 32-row tiles: query tile i is dead after step i, and wave 7 puts the NEXT
+//     item's tile i there right away by LDS-DMA (with its O tile into a staging tile and its lse values), a whole item
+//     ahead of the first reader; two steps later it turns dO and O into delta = rowsum(dO * O) and lse into lse * log2(e)
+//     (double-buffered by item parity).  The workers fetch their next K / V rows a step before the item ends.
+// One barrier per step (`s_waitcnt lgkmcnt(0); s_barrier`: no vmcnt, prefetches and result stores stay in flight across it),
+// one more at the top of an item.  The next query tile's score products are issued before the barrier.
+// LDS: 2 x 28 KB ring + 2 x 15.75 KB dS exchange + 8 x 4 KB per-wave staging + 3.5 KB lse / delta + 12 KB O staging = 135 KB.
 constexpr int MG_LP = 224;
 constexpr int MG_TILE = 32 * 64;                // elements of one [32][64] bf16 tile
-constexpr int MG_SLOT_BYTES = 32 * 64 * 4;      // one fp32 dQ^T partial
-constexpr int MG_SCR_LD = 36;                   // dS scratch: [32 keys][36] bf16 (72-byte rows: conflict-free 8-byte stores)
-constexpr size_t MG_LDS_BYTES = (size_t)2 * 7 * MG_TILE * 2 + 7 * MG_SLOT_BYTES + 8 * MA_STAGE_ELEMS * 2 + 2 * 2 * MG_LP * 4 + 3 * MG_TILE * 2;
+constexpr int MG_SCR_LD = 36;                   // a dS tile in the exchange area: [32 keys][36] bf16 (72-byte rows: conflict-free 8-byte stores)
+constexpr int MG_SCR_BYTES = 32 * MG_SCR_LD * 2;             // 2304
+constexpr int MG_XCH_BYTES = 7 * 2 * MG_SCR_BYTES;           // [worker][buffer][2304]: a worker's two buffers also hold its V tile (4 KB) at the top of an item
+constexpr size_t MG_LDS_BYTES = (size_t)2 * 7 * MG_TILE * 2 + MG_XCH_BYTES + 8 * MA_STAGE_ELEMS * 2 + 2 * 2 * MG_LP * 4 + 4 * MG_TILE * 2 + MG_TILE * 2;
 
 __device__ inline void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // n / d for 0 <= n < 2^24 with inv = 1.0f / d (an integer division is ~40 vector instructions; the item -> (sequence, head) and
@@ -903,29 +905,31 @@ __device__ inline void mg_store_rows_lin(bf16raw* stg, const f32x16 (&acc)[2], f
   }
   wave_lds_sync();
 }
+
 #ifndef VTX_STREAM_ABLATE
-#define VTX_STREAM_ABLATE 0   // timing experiments only (wrong results): 1 = the feeder fetches nothing after item 0, 2 = no products /
-#endif                        // softmax in the workers, 4 = no dq sums / stores, 8 = no K / V refetch and no dk / dv stores
+#define VTX_STREAM_ABLATE 0   // timing experiments only (wrong results): 1 = the feeder requests nothing after item 0, 2 = no products /
+#endif                        // softmax in the workers, 4 = no dq products / stores, 8 = no K / V refetch and no dk / dv stores
 
 template <int NT_>
 __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
                                                                           const bf16raw* __restrict__ o, const bf16raw* __restrict__ dout,
                                                                           const float* __restrict__ lse, bf16raw* __restrict__ dqkv,
                                                                           bf16raw* __restrict__ dqkv_cls, long long* __restrict__ trace) {
-  static_assert(NT_ == 7, "seven 32-row tiles (193 .. 224 tokens): seven workers + the feeder");
+  static_assert(NT_ == 7, "seven 32-row tiles (193 .. 224 tokens): seven workers + wave 7");
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int D = p.H * 64, items = p.S * p.H;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16raw* Qs = reinterpret_cast<bf16raw*>(sm_raw);
   bf16raw* Os = Qs + NT_ * MG_TILE;                 // dO
-  char* slots = reinterpret_cast<char*>(Os + NT_ * MG_TILE);
-  bf16raw* stg = reinterpret_cast<bf16raw*>(slots + 7 * MG_SLOT_BYTES) + wave * MA_STAGE_ELEMS;
-  float* LD = reinterpret_cast<float*>(slots + 7 * MG_SLOT_BYTES + 8 * MA_STAGE_ELEMS * 2);   // [parity][lse2 | delta][224]
+  char* xch = reinterpret_cast<char*>(Os + NT_ * MG_TILE);                 // dS exchange: [worker][buffer][32 keys][36]
+  bf16raw* stg0 = reinterpret_cast<bf16raw*>(xch + MG_XCH_BYTES);           // [8 waves][32][64] staging tiles
+  bf16raw* stg = stg0 + wave * MA_STAGE_ELEMS;
+  float* LD = reinterpret_cast<float*>(stg0 + 8 * MA_STAGE_ELEMS);          // [parity][lse2 | delta][224]
   const float c2 = p.scale * LOG2E;
   const int stride = gridDim.x;
   if (blockIdx.x >= items) return;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  // VTX_STREAM_TRACE (variant builds, tools/attn_timeline.py): shader-clock stamps of wave 0 (a worker) and wave 7 (the feeder)
+  // VTX_STREAM_TRACE (variant builds, tools/attn_timeline.py): shader-clock stamps of wave 0 (a worker) and wave 7
   // of workgroup 0 for its first four items: trace[((role * 4 + item) * 8 + step) * 8 + point]
 #ifdef VTX_STREAM_TRACE
   int tr_item = 0;
@@ -938,67 +942,50 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
 #else
 #define MG_STAMP(role_, step_, pt_)
 #endif
-#ifndef VTX_STREAM_STAGGER
-#define VTX_STREAM_STAGGER 0
-#endif
-#ifndef VTX_STREAM_STAGGER_SLEEP
-#define VTX_STREAM_STAGGER_SLEEP 60
-#endif
-  if (VTX_STREAM_STAGGER > 0) {
-    for (int k = (int)(blockIdx.x % VTX_STREAM_STAGGER); k > 0; --k) __builtin_amdgcn_s_sleep(VTX_STREAM_STAGGER_SLEEP);
-  }
-
-  // Sum of the seven partials of query tile i: this wave takes query rows 4 * wave .. + 3, a lane one row and four
-  // consecutive columns.  A partial is stored in accumulator order, 16-byte chunk (j, lane) at position
-  // j * 64 + 32 * half + ((q ^ half) ^ 2 j)  (q = lane & 31, half = lane >> 5; chunk j = registers 4 (j & 3) .. + 3 of C tile
-  // j >> 2 = columns d0 = 4 (2 j + half) .. + 3 of query q): both the writers' and the readers' lane groups touch 16 distinct
-  // chunk positions mod 16.
-  const int rq = 4 * wave + (lane >> 4), rc = lane & 15;
-  const unsigned red_off = (unsigned)((((rc >> 1) * 64 + 32 * (rc & 1) + ((rq ^ (rc & 1)) ^ (rc & 14))) * 16));
-  // dq rows of this lane: query row i * 32 + rq of the item -> dq_lin + i * dq_step (elements), row 0 of the sequence -> dq_row0
-  // (set per item by set_dq_rows)
-  bf16raw* dq_lin = nullptr;
-  bf16raw* dq_row0 = nullptr;
-  long dq_step = 0;
-  auto set_dq_rows = [&](int s, int h, const RowLin& li) {
-    dq_lin = dqkv + (li.base + (long)rq * li.stride) * p.ld_dqkv + h * 64 + 4 * rc;
-    dq_row0 = (p.mode == VTX_ATTN_SPACE ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + li.row0 * p.ld_dqkv) + h * 64 + 4 * rc;
-    dq_step = 32 * li.stride * p.ld_dqkv;
-  };
-  auto reduce_store = [&](int i) {
-    const char* sb = slots + red_off;
-    float4 a = *reinterpret_cast<const float4*>(sb);
-#pragma unroll
-    for (int w = 1; w < 7; ++w) {
-      const float4 b = *reinterpret_cast<const float4*>(sb + w * MG_SLOT_BYTES);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    bf16raw* dst = (i == 0 && rq == 0) ? dq_row0 : dq_lin + i * dq_step;
-    if (i * 32 + rq < p.L) {
-      union { bf16x4 v; uint2 u; } w4;
-      w4.v[0] = (__bf16)(a.x * p.scale); w4.v[1] = (__bf16)(a.y * p.scale);
-      w4.v[2] = (__bf16)(a.z * p.scale); w4.v[3] = (__bf16)(a.w * p.scale);
-      *reinterpret_cast<uint2*>(dst) = w4.u;
-    }
-  };
   const float invH = 1.0f / (float)p.H, invT = p.mode == VTX_ATTN_SPACE ? 1.0f / (float)p.T : 1.0f;
+  // transpose-read address (bytes) of a dS tile in the exchange area: rows = keys 16 s2 + 4 half + .. (+ 8), columns = queries
+  const unsigned scr_r = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * (MG_SCR_LD * 2) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
 
-  if (wave == MF_LOADER) {                          // ---------------------------------------------------------------- feeder
-    // Everything the feeder brings in travels HBM -> LDS by LDS-DMA (no registers, any number of requests in flight): the
-    // Q / dO tile of query tile i of the NEXT item goes straight into ring slot i right after A(i), its O tile into one of
-    // three staging tiles, its lse values into the other parity's lse array -- 13 wave-instructions per step, a whole item
-    // ahead of their first reader.  Two steps later (`s_waitcnt vmcnt(13)`: requests retire in issue order, the 13 of the
-    // step in between may still be in flight) the feeder turns dO (ring) and O (staging) into delta = rowsum(dO * O) and
-    // lse into lse * log2(e).  The schedule rolls over the item boundary: tile j = i - 2 (mod 7), so tiles 5 and 6 of an
-    // item are finished during steps 0 and 1 of that item (their first readers are steps 5 and 6).  The requests are inline
-    // asm: hipcc waits `vmcnt(0)` before LDS reads while a DMA it knows of is in flight, which would park the feeder -- and
-    // with it every barrier -- on the requests it has just issued.
+  // O staging tiles [4][32][64]: query tile t of local item m sits in tile (t - m) & 3 (requested at step t of item m - 1, turned into
+  // delta three steps later while the requests of the three steps in between are in flight or pending)
+  bf16raw* stO = reinterpret_cast<bf16raw*>(reinterpret_cast<char*>(LD) + 2 * 2 * MG_LP * 4);
+  // delta = rowsum(dO * O) and lse * log2(e) of query tile t: dO from ring tile t, O from staging tile `ost`, into the arrays of
+  // parity `par`; the lanes of row group `grp` (rows 8 grp .. + 7; -1: all) write.  Row-per-lane arithmetic of the other kernels
+  // (same delta bit for bit).
+  auto finish_tile = [&](int t, const bf16raw* ost, int par, int grp, const FragOff& f) {
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dl = frag_dot2(frag_rows_o(Os, t * 32, ks, f), frag_rows_o(ost, 0, ks, f), dl);
+    dl += __shfl_xor(dl, 32, 64);
+    if (lane < 32 && (grp < 0 || (lane >> 3) == grp)) {
+      const int row = t * 32 + lane;
+      float* lp = LD + par * 2 * MG_LP + row;
+      const float raw = *lp;
+      *lp = row < p.L ? raw * LOG2E : 1e30f;
+      lp[MG_LP] = row < p.L ? dl : 0.f;
+    }
+  };
+  // dq tiles leave wave 7 as bf16 in one of two staging tiles (its own and one more; by the parity of the running step count) and
+  // are stored by workers 0 .. 3 two steps later, 8 whole rows each: wave 7 is the busiest wave of a step
+  // (second tile addressed as first + parity * distance: indexing an array of two pointers makes the access a FLAT one, and a FLAT
+  // load waits for vmcnt(0))
+  bf16raw* dqs0 = stg0 + MF_LOADER * MA_STAGE_ELEMS;
+  constexpr int dqs_dist = (8 - MF_LOADER) * MA_STAGE_ELEMS + (2 * 2 * MG_LP * 4 + 4 * MG_TILE * 2) / 2;   // elements from tile 0 to tile 1
+
+  if (wave == MF_LOADER) {                          // ------------------------------------------------- wave 7: feeds, and owns dq
+    // Everything this wave brings in travels HBM -> LDS by LDS-DMA (no registers, any number of requests in flight): the
+    // Q / dO tile of query tile i of the NEXT item goes straight into ring slot i right after the barrier of step i, its O
+    // tile into one of three staging tiles, its lse values into the other parity's lse array -- 13 wave-instructions per
+    // step, a whole item ahead of their first reader.  Two steps later (`s_waitcnt vmcnt(13)`: requests retire in issue
+    // order, the 13 of the step in between may still be in flight; the dq stores in between only make the wait stricter)
+    // dO (ring) and O (staging) become delta = rowsum(dO * O) and lse becomes lse * log2(e).  The schedule rolls over the
+    // item boundary: tile j = i - 2 (mod 7), so tiles 5 and 6 of an item are finished during steps 0 and 1 of that item
+    // (their first readers are steps 5 and 6).  The requests are inline asm: hipcc waits `vmcnt(0)` before LDS reads while
+    // a DMA it knows of is in flight, which would park this wave -- and with it every barrier -- on what it has just issued.
     typedef __attribute__((address_space(3))) char lds_char;
-    bf16raw* stO = reinterpret_cast<bf16raw*>(reinterpret_cast<char*>(LD) + 2 * 2 * MG_LP * 4);      // [3][32][64] bf16
-    const FragOff ffo = make_frag_off(lane);
-    // Row addresses in closed form (a 64-bit multiply-add per request otherwise: the 13 requests of a step took 1600 cycles):
-    // row r = 8 G + lane / 8 of a sequence sits at p1 + G * inc8 except row 0 (p0) and the clamped rows beyond L - 1 (plast);
-    // the chunk swizzle of the destination row only depends on the parity of G.
+    FragOff ffo = make_frag_off(lane);
+    // Row addresses in closed form: row r = 8 G + lane / 8 of a sequence sits at p1 + G * inc8 except row 0 (p0) and the
+    // clamped rows beyond L - 1 (plast); the chunk swizzle of the destination row only depends on the parity of G.
     struct Src { const bf16raw* p1; const bf16raw* p0; const bf16raw* plast; long inc8; };
     const int rl8 = lane >> 3, pc = lane & 7;
     const int swz[2] = {(pc ^ sw_of(rl8)) << 3, (pc ^ sw_of(8 + rl8)) << 3};
@@ -1039,35 +1026,21 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(lsd + t * 32));
       if (lane < 32) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
     };
-    // delta and scaled lse of query tile t: dO from ring tile t, O from staging tile `ost`, into the arrays of parity `par`
-    auto finish_tile = [&](int t, const bf16raw* ost, int par) {
-      float dl = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dl = frag_dot2(frag_rows_o(Os, t * 32, ks, ffo), frag_rows_o(ost, 0, ks, ffo), dl);
-      dl += __shfl_xor(dl, 32, 64);
-      if (lane < 32) {
-        const int row = t * 32 + lane;
-        float* lp = LD + par * 2 * MG_LP + row;
-        const float raw = *lp;
-        *lp = row < p.L ? raw * LOG2E : 1e30f;
-        lp[MG_LP] = row < p.L ? dl : 0.f;
-      }
-    };
     int item = blockIdx.x, par = 0;
     int s = mg_div(item, p.H, invH), h = item - s * p.H;
     RowLin li = mg_lin_in(p, s, invT), lo = mg_lin_out(p, s, invT);
-    set_dq_rows(s, h, li);
-    // item 0: all seven tiles at once; O tiles 0 .. 4 park in the (still unused) partial slots, 5 and 6 in their staging tiles
+    // item 0: all seven tiles at once, O tiles parked in the (still unused) exchange area
     {
-      bf16raw* park = reinterpret_cast<bf16raw*>(slots);
+      bf16raw* park = reinterpret_cast<bf16raw*>(xch);
       set_item(s, h, li, lo);
 #pragma unroll
-      for (int t = 0; t < NT_; ++t) dma_item_tile(t, t < 5 ? park + t * MG_TILE : stO + (t % 3) * MG_TILE, LD);
+      for (int t = 0; t < NT_; ++t) dma_item_tile(t, park + t * MG_TILE, LD);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int t = 0; t < 5; ++t) finish_tile(t, park + t * MG_TILE, 0);
+      for (int t = 0; t < NT_; ++t) finish_tile(t, park + t * MG_TILE, 0, -1, ffo);
     }
-    int k3 = 7 % 3;                                 // (7 (n + 1) + i) % 3: staging tile of the request of step i
+    int nn = 1;                                     // local index of the item the requests are for (mod 4)
+    int q2 = 0;                                     // (7 n + i) & 1: dq staging tile of step i
     mg_barrier();                                   // P: item 0 is in the ring
     while (true) {
       const int next = item + stride;
@@ -1076,34 +1049,74 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       const RowLin lin = mg_lin_in(p, sn, invT), lon = mg_lin_out(p, sn, invT);
       if (more) set_item(sn, hn, lin, lon);
 #pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ffo.cols[i >> 1][i & 1]));
+      MG_STAMP(1, 7, 0)
+      mg_barrier();                                 // T: the workers' K tiles are in their staging tiles
+      // the item's K^T fragments: A operands of dQ^T += K_kt^T dS_kt^T for all seven key tiles
+      bf16x8 ktf[NT_][2][2];
+#pragma unroll
+      for (int kt = 0; kt < NT_; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) ktf[kt][s2][n2] = frag_cols_o(stg0 + kt * MA_STAGE_ELEMS, 16 * s2, n2, ffo);
+      MG_STAMP(1, 7, 1)
+#pragma unroll
       for (int i = 0; i < NT_; ++i) {
         MG_STAMP(1, i, 0)
-        mg_barrier();                               // B(i): nobody reads ring tile i any more
+        mg_barrier();                               // A(i): the dS tiles of step i are in buffer i & 1; nobody reads ring tile i any more
         MG_STAMP(1, i, 1)
-        mg_barrier();                               // A(i): the partials of query tile i are in LDS
-        MG_STAMP(1, i, 2)
-        if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i);
+        if (!(VTX_STREAM_ABLATE & 4)) {
+          f32x16 acc[2];
+          zero16(acc[0]); zero16(acc[1]);
+#pragma unroll
+          for (int kt = 0; kt < NT_; ++kt) {
+            const char* t0 = xch + (kt * 2 + (i & 1)) * MG_SCR_BYTES + scr_r;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              union { bf16x8 v; s16x4 hh[2]; } u;
+              u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(t0 + s2 * 16 * MG_SCR_LD * 2));
+              u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (s16x4 __attribute__((address_space(3)))*)(t0 + s2 * 16 * MG_SCR_LD * 2 + 8 * MG_SCR_LD * 2));
+#pragma unroll
+              for (int n2 = 0; n2 < 2; ++n2) acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[kt][s2][n2], u.v, acc[n2], 0, 0, 0);
+            }
+          }
+          MG_STAMP(1, i, 2)
+          // dQ^T tile (lane & 31 = query row, registers = 64 columns) -> bf16 [32][64] staging tile, scaled
+          bf16raw* dst = dqs0 + q2 * dqs_dist;
+          const int row = lane & 31;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int col = nt * 32 + 8 * g + 4 * (lane >> 5);
+              union { bf16x4 v; uint2 u; } w;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) w.v[j] = (__bf16)(acc[nt][4 * g + j] * p.scale);
+              *reinterpret_cast<uint2*>(dst + sw_off(row, col)) = w.u;
+            }
+        }
+        q2 ^= 1;
         MG_STAMP(1, i, 3)
         if (!(VTX_STREAM_ABLATE & 1)) {
-          const int kf2 = k3 == 2 ? 0 : k3 + 1;     // (k3 - 2) mod 3: the staging tile of the request two steps ago
-          if (i < 2 || more) {
-            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-            MG_STAMP(1, i, 4)
-            finish_tile(i < 2 ? i + 5 : i - 2, stO + kf2 * MG_TILE, i < 2 ? par : par ^ 1);
-          }
+          // the requests of step i - 2 are complete behind this wait (those of step i - 1 may be in flight); the barrier of the next
+          // step publishes that, and workers 0 .. 3 turn the tile into delta / lse * log2(e) behind it
+          asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+          MG_STAMP(1, i, 4)
           MG_STAMP(1, i, 5)
-          if (more) dma_item_tile(i, stO + k3 * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
+          if (more) dma_item_tile(i, stO + ((i - nn) & 3) * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
           MG_STAMP(1, i, 6)
         }
-        k3 = k3 == 2 ? 0 : k3 + 1;
       }
+      nn = (nn + 1) & 3;
       if (!more) break;
       item = next; s = sn; h = hn; li = lin; lo = lon; par ^= 1;
-      set_dq_rows(s, h, li);
 #ifdef VTX_STREAM_TRACE
       ++tr_item;
 #endif
     }
+    mg_barrier();                                   // D: the last dq tile is in its staging tile
     return;
   }
 
@@ -1113,18 +1126,15 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
   int s = mg_div(item, p.H, invH), h = item - s * p.H;
   RowLin li = mg_lin_in(p, s, invT);
   const int key = wave * 32 + (lane & 31);
-  // K_w / V_w arrive as whole rows (kr / vr: row 8 g + lane / 8, chunk lane % 8) and become fragments through the staging tile
+  // K_w / V_w arrive as whole rows (kr / vr: row 8 g + lane / 8, chunk lane % 8) and become fragments through LDS
   u32x4 kr[4], vr[4];
   mg_load_tile_raw(kr, qkv, p.ld_qkv, D + h * 64, li, wave * 32, p.L, lane);
   mg_load_tile_raw(vr, qkv, p.ld_qkv, 2 * D + h * 64, li, wave * 32, p.L, lane);
   bf16x8 kf[4], vf[4];
   const bool ragged_wave = wave == NT_ - 1 && (p.L & 31) != 0;
-  // dS scratch addresses (bytes from the wave's staging tile): stores [key][query], 8 bytes = 4 queries; transpose reads
-  char* scr = reinterpret_cast<char*>(stg);
+  // this worker's part of the exchange area: two dS buffers ([key][query], 8-byte stores of 4 queries), also its V tile at the top
+  char* myx = xch + wave * 2 * MG_SCR_BYTES;
   const unsigned scr_w = (unsigned)((lane & 31) * (MG_SCR_LD * 2) + 8 * (lane >> 5));
-  const unsigned scr_r = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * (MG_SCR_LD * 2) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
-  const unsigned slot_w = (unsigned)((((lane & 31) ^ (lane >> 5)) + 32 * (lane >> 5)) * 16);
-  char* my_slot = slots + wave * MG_SLOT_BYTES;
   auto scores = [&](int qt, f32x16& st, f32x16& dp) {
     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Qs, qt * 32, 0, fo), kf[0], zero, 0, 0, 0);
     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, 0, fo), vf[0], zero, 0, 0, 0);
@@ -1134,7 +1144,23 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Os, qt * 32, ks, fo), vf[ks], dp, 0, 0, 0);
     }
   };
-  // (the first item's K / V fragments are complete before the loop is entered: the loop header then needs no wait for them on
+  // dq rows: staging tile row r = 8 g + lane / 8 of query tile t -> dq_lin + (4 t + g) * dq_step8, row 0 of the sequence -> dq_row0
+  bf16raw *dq_lin = nullptr, *dq_row0 = nullptr, *dq_lin_prev = nullptr, *dq_row0_prev = nullptr;
+  long dq_step8 = 0, dq_step8_prev = 0;
+  bool have_prev = false;
+  int nloc = 0;                                     // local item index mod 4
+  int rp = 0;                                       // (7 n + k) & 1 at step k: staging tile of the dq tile written two steps ago
+  auto store_dq = [&](int t, bool prev) {           // workers 0 .. 3: 8 rows each of query tile t (of the previous item: prev)
+    if (!(VTX_STREAM_ABLATE & 4)) {                 // (no branch around the LDS read: it is scheduled into the step's other work)
+      const int r = (wave & 3) * 8 + (lane >> 3), c = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(dqs0 + rp * dqs_dist + r * 64 + ((c ^ sw_of(r)) << 3));
+      bf16raw* lin = prev ? dq_lin_prev : dq_lin;
+      bf16raw* dst = lin + (4 * t + (wave & 3)) * (prev ? dq_step8_prev : dq_step8);
+      if (t == 0 && r == 0) dst = prev ? dq_row0_prev : dq_row0;
+      if (wave < 4 && t * 32 + r < p.L) *reinterpret_cast<uint4*>(dst + c * 8) = v;
+    }
+  };
+  // (the first item's K / V rows are complete before the loop is entered: the loop header then needs no wait for them on
   // either path -- a wait there would, on the back edge, drain the dk / dv stores of the item before)
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kr[ks]), "+v"(vr[ks]));
@@ -1145,24 +1171,19 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.cols[i >> 1][i & 1]));
     MG_STAMP(0, 7, 0)
-    // K_w: row fragments (B operand of S = Q K^T) and transposed fragments (A operand of dQ^T = K^T dS^T), V_w: row fragments,
-    // through the private staging tile
-    set_dq_rows(s, h, li);
+    dq_lin = dqkv + (li.base + (long)(lane >> 3) * li.stride) * p.ld_dqkv + h * 64;
+    dq_row0 = (p.mode == VTX_ATTN_SPACE ? dqkv_cls + (long)s * p.ld_dqkv : dqkv + li.row0 * p.ld_dqkv) + h * 64;
+    dq_step8 = 8 * li.stride * p.ld_dqkv;
+    // K_w into the staging tile (wave 7 takes its K^T fragments from there behind barrier T); V_w into this worker's exchange
+    // buffers -- behind T as well: until then wave 7 may still be reading the dS tiles of the previous item's last step
     mg_raw_to_tile(stg, kr, lane);
-    wave_lds_sync();
-    bf16x8 ktf[2][2];
+    mg_barrier();                                   // T
+    mg_raw_to_tile(reinterpret_cast<bf16raw*>(myx), vr, lane);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_rows_o(stg, 0, ks, fo);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2) ktf[s2][n2] = frag_cols_o(stg, 16 * s2, n2, fo);
-    wave_lds_sync();
-    mg_raw_to_tile(stg, vr, lane);
     wave_lds_sync();
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) vf[ks] = frag_rows_o(stg, 0, ks, fo);
-    wave_lds_sync();
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = frag_rows_o(reinterpret_cast<bf16raw*>(myx), 0, ks, fo);
     const float* Lc = LD + par * 2 * MG_LP;
     const float* Dc = Lc + MG_LP;
     const int next = item + stride;
@@ -1172,106 +1193,89 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
     zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
     f32x16 st = zero, dp = zero;
     if (!(VTX_STREAM_ABLATE & 2)) scores(0, st, dp);
+    wave_lds_sync();                                // V fragments are in registers before step 0 writes dS over the V tile
     MG_STAMP(0, 7, 1)
 #pragma unroll
     for (int i = 0; i < NT_; ++i) {
       MG_STAMP(0, i, 0)
-      f32x16 pq[2] = {zero, zero};
+      if (i >= 2) store_dq(i - 2, false);
+      else if (have_prev) store_dq(i + 5, true);
+      rp ^= 1;
+      f32x16 stn = zero, dpn = zero;
       if (!(VTX_STREAM_ABLATE & 2)) {
-      float pr[16], ds[16];
+        float pr[16], ds[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int qrow = i * 32 + 8 * g + 4 * (lane >> 5);
-        const float4 l4 = *reinterpret_cast<const float4*>(Lc + qrow);
-        const float4 d4 = *reinterpret_cast<const float4*>(Dc + qrow);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int g = 0; g < 4; ++g) {
+          const int qrow = i * 32 + 8 * g + 4 * (lane >> 5);
+          const float4 l4 = *reinterpret_cast<const float4*>(Lc + qrow);
+          const float4 d4 = *reinterpret_cast<const float4*>(Dc + qrow);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          const float e = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lv[j]));
-          pr[r] = e;
-          ds[r] = e * (dp[r] - dvv[j]);              // the softmax scale is applied once, at the stores
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lv[j]));
+            pr[r] = e;
+            ds[r] = e * (dp[r] - dvv[j]);            // the softmax scale is applied once, at the stores
+          }
         }
+        bf16x8 pb[2], db[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) db[s2] = pack8(ds + 8 * s2);
+        {
+          // dS^T for wave 7: padded keys (only the last key tile has any) must not reach dq -- their dk / dv columns are never
+          // stored, but a dq row sums over all keys
+          bf16x8 dm[2] = {db[0], db[1]};
+          if (ragged_wave && key >= p.L) { dm[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; dm[1] = dm[0]; }
+          union { bf16x8 v; uint2 u[2]; } x0, x1;
+          x0.v = dm[0]; x1.v = dm[1];
+          char* dst = myx + (i & 1) * MG_SCR_BYTES + scr_w;
+          *reinterpret_cast<uint2*>(dst) = x0.u[0];          // queries  0 ..  3 (+ 4 half)
+          *reinterpret_cast<uint2*>(dst + 16) = x0.u[1];     //          8 .. 11
+          *reinterpret_cast<uint2*>(dst + 32) = x1.u[0];     //         16 .. 19
+          *reinterpret_cast<uint2*>(dst + 48) = x1.u[1];     //         24 .. 27
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) pb[s2] = pack8(pr + 8 * s2);
+        MG_STAMP(0, i, 1)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) {
+            dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, i * 32 + 16 * s2, n2, fo), pb[s2], dv[n2], 0, 0, 0);
+            dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, i * 32 + 16 * s2, n2, fo), db[s2], dk[n2], 0, 0, 0);
+          }
+        MG_STAMP(0, i, 2)
+        if (i + 1 < NT_) scores(i + 1, stn, dpn);   // the next query tile's products are on the matrix pipe across the barrier
       }
-      // order: dS on its way through the scratch first, the dV products while it travels, then the dQ partial (the hand-over
-      // below waits for it), the dK products last (their accumulators are not read before the next step)
-      bf16x8 pb[2], db[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) db[s2] = pack8(ds + 8 * s2);
-      {
-        // dS^T: padded keys (only the last key tile has any) must not reach dq -- their dk / dv columns are never stored,
-        // but a dq row sums over all keys
-        bf16x8 dm[2] = {db[0], db[1]};
-        if (ragged_wave && key >= p.L) { dm[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; dm[1] = dm[0]; }
-        union { bf16x8 v; uint2 u[2]; } x0, x1;
-        x0.v = dm[0]; x1.v = dm[1];
-        *reinterpret_cast<uint2*>(scr + scr_w) = x0.u[0];          // queries  0 ..  3 (+ 4 half)
-        *reinterpret_cast<uint2*>(scr + scr_w + 16) = x0.u[1];     //          8 .. 11
-        *reinterpret_cast<uint2*>(scr + scr_w + 32) = x1.u[0];     //         16 .. 19
-        *reinterpret_cast<uint2*>(scr + scr_w + 48) = x1.u[1];     //         24 .. 27
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) pb[s2] = pack8(pr + 8 * s2);
-      MG_STAMP(0, i, 1)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-          dv[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Os, i * 32 + 16 * s2, n2, fo), pb[s2], dv[n2], 0, 0, 0);
-      wave_lds_sync();
-      MG_STAMP(0, i, 2)
-      bf16x8 dbt[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { bf16x8 v; s16x4 hh[2]; } u;
-        u.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4 __attribute__((address_space(3)))*)(scr + scr_r + s2 * 16 * MG_SCR_LD * 2));
-        u.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4 __attribute__((address_space(3)))*)(scr + scr_r + s2 * 16 * MG_SCR_LD * 2 + 8 * MG_SCR_LD * 2));
-        dbt[s2] = u.v;
-      }
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2) {
-        pq[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][n2], dbt[0], zero, 0, 0, 0);
-        pq[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][n2], dbt[1], pq[n2], 0, 0, 0);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-          dk[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Qs, i * 32 + 16 * s2, n2, fo), db[s2], dk[n2], 0, 0, 0);
-      }
-      MG_STAMP(0, i, 3)
-      mg_barrier();                                 // B(i): the partials of query tile i - 1 have been read
-      MG_STAMP(0, i, 4)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float4 v;
-        v.x = pq[j >> 2][4 * (j & 3)]; v.y = pq[j >> 2][4 * (j & 3) + 1];
-        v.z = pq[j >> 2][4 * (j & 3) + 2]; v.w = pq[j >> 2][4 * (j & 3) + 3];
-        *reinterpret_cast<float4*>(my_slot + j * 1024 + (slot_w ^ (unsigned)(32 * j))) = v;
-      }
-      MG_STAMP(0, i, 5)
-      mg_barrier();                                 // A(i)
-      MG_STAMP(0, i, 6)
-      // the next query tile's score products go to the matrix pipe first, the sums and the store of this one run beside them
-      // (issued BEFORE the hand-over they cost 32 more live registers than two waves per SIMD have: spills in the step loop)
-      if (i + 1 < NT_ && !(VTX_STREAM_ABLATE & 2)) scores(i + 1, st, dp);
-      if (i + 1 == NT_ - 1 && !(VTX_STREAM_ABLATE & 8)) {
-        // K_w / V_w have had their last use: the next item's rows are requested now, a whole step ahead of their first use
+      if ((i == NT_ - 3 || i == NT_ - 2) && !(VTX_STREAM_ABLATE & 8)) {
+        // the next item's K_w rows are requested two steps, its V_w rows one step before the item ends (8 requests per worker in
+        // one step keep the vector memory pipeline of the CU busy for 1500 cycles with every worker waiting to issue)
         int nxo = nx;                               // opaque: the addresses are built here, not at the top of the item (spills)
         asm volatile("" : "+s"(nxo));
         const int sn = mg_div(nxo, p.H, invH), hn = nxo - sn * p.H;
         const RowLin lin = mg_lin_in(p, sn, invT);
-        mg_load_tile_raw(kr, qkv, p.ld_qkv, D + hn * 64, lin, wave * 32, p.L, lane);
-        mg_load_tile_raw(vr, qkv, p.ld_qkv, 2 * D + hn * 64, lin, wave * 32, p.L, lane);
+        if (i == NT_ - 3) mg_load_tile_raw(kr, qkv, p.ld_qkv, D + hn * 64, lin, wave * 32, p.L, lane);
+        else mg_load_tile_raw(vr, qkv, p.ld_qkv, 2 * D + hn * 64, lin, wave * 32, p.L, lane);
       }
-      if (!(VTX_STREAM_ABLATE & 4)) reduce_store(i);
-      MG_STAMP(0, i, 7)
+      MG_STAMP(0, i, 3)
+      mg_barrier();                                 // A(i)
+      MG_STAMP(0, i, 4)
+      // delta / lse of the tile whose requests wave 7 saw complete before this barrier: query tile i - 3 of the next item (i >= 3) or
+      // tile i + 4 of this one (requested during the item before); workers 0 .. 3 write eight rows each
+      // (every worker runs the ~45 instructions -- no branch, so they are scheduled into the next step's work instead of standing
+      // alone behind the barrier as an 850-cycle latency chain; no lane of workers 4 .. 6 belongs to a row group 4 .. 6)
+      if (!(VTX_STREAM_ABLATE & 1)) {
+        if (i >= 3) {
+          if (more) finish_tile(i - 3, stO + ((i - 3 - (nloc + 1)) & 3) * MG_TILE, par ^ 1, wave, fo);
+        } else if (have_prev) {
+          finish_tile(i + 4, stO + ((i + 4 - nloc) & 3) * MG_TILE, par, wave, fo);
+        }
+      }
+      st = stn;
+      dp = dpn;
     }
-    // The next item's K / V fragments are waited for HERE (requested a step ago; the counted wait the compiler derives only
-    // covers what is older than the two dq stores issued since), in front of the dk / dv stores: requests retire in order,
-    // so a wait at the top of the next item would also drain these eight stores.
+    // The next item's K / V rows are waited for HERE (requested a step ago), in front of the dk / dv stores: requests retire in
+    // order, so a wait at the top of the next item would also drain these eight stores.
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kr[ks]), "+v"(vr[ks]));
     MG_STAMP(0, 7, 2)
@@ -1283,16 +1287,23 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
                                   : p_lin;
       const long step8 = 8 * li.stride * p.ld_dqkv;
       const int nrows = p.L - wave * 32;
+      // (the staging tile still holds K_w, but wave 7 took its fragments right behind barrier T, seven barriers ago)
       mg_store_rows_lin(stg, dk, p.scale, lane, p_lin, step8, p_row0, nrows);
       mg_store_rows_lin(stg, dv, 1.0f, lane, p_lin + D, step8, p_row0 + D, nrows);
     }
     MG_STAMP(0, 7, 3)
     if (!more) break;
+    dq_lin_prev = dq_lin; dq_row0_prev = dq_row0; dq_step8_prev = dq_step8; have_prev = true;
+    nloc = (nloc + 1) & 3;
     item = next; s = mg_div(item, p.H, invH); h = item - s * p.H; li = mg_lin_in(p, s, invT); par ^= 1;
 #ifdef VTX_STREAM_TRACE
     ++tr_item;
 #endif
   }
+  store_dq(5, false);                               // the last item's last two dq tiles
+  rp ^= 1;
+  mg_barrier();                                     // D
+  store_dq(6, false);
 }
 
 // =====================================================================================
