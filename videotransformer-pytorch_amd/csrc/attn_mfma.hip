@@ -906,6 +906,9 @@ __device__ inline void mg_store_rows_lin(bf16raw* stg, const f32x16 (&acc)[2], f
   wave_lds_sync();
 }
 
+#ifndef VTX_STREAM_KV_AHEAD
+#define VTX_STREAM_KV_AHEAD 2 // the workers request their next K rows this many steps (+ 1) and their next V rows this many steps before the item ends
+#endif
 #ifndef VTX_STREAM_ABLATE
 #define VTX_STREAM_ABLATE 0   // timing experiments only (wrong results): 1 = the feeder requests nothing after item 0, 2 = no products /
 #endif                        // softmax in the workers, 4 = no dq products / stores, 8 = no K / V refetch and no dk / dv stores
@@ -1247,14 +1250,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
         MG_STAMP(0, i, 2)
         if (i + 1 < NT_) scores(i + 1, stn, dpn);   // the next query tile's products are on the matrix pipe across the barrier
       }
-      if ((i == NT_ - 3 || i == NT_ - 2) && !(VTX_STREAM_ABLATE & 8)) {
-        // the next item's K_w rows are requested two steps, its V_w rows one step before the item ends (8 requests per worker in
+      if ((i == NT_ - 1 - VTX_STREAM_KV_AHEAD || i == NT_ - VTX_STREAM_KV_AHEAD) && !(VTX_STREAM_ABLATE & 8)) {
+        // the next item's K_w rows are requested two steps, its V_w rows one step before the item ends (no gain from more; 8 requests per worker in
         // one step keep the vector memory pipeline of the CU busy for 1500 cycles with every worker waiting to issue)
         int nxo = nx;                               // opaque: the addresses are built here, not at the top of the item (spills)
         asm volatile("" : "+s"(nxo));
         const int sn = mg_div(nxo, p.H, invH), hn = nxo - sn * p.H;
         const RowLin lin = mg_lin_in(p, sn, invT);
-        if (i == NT_ - 3) mg_load_tile_raw(kr, qkv, p.ld_qkv, D + hn * 64, lin, wave * 32, p.L, lane);
+        if (i == NT_ - 1 - VTX_STREAM_KV_AHEAD) mg_load_tile_raw(kr, qkv, p.ld_qkv, D + hn * 64, lin, wave * 32, p.L, lane);
         else mg_load_tile_raw(vr, qkv, p.ld_qkv, 2 * D + hn * 64, lin, wave * 32, p.L, lane);
       }
       MG_STAMP(0, i, 3)
