@@ -50,7 +50,7 @@ for it in (1, 2, 3):
     for pt in range(1, 5):
         print(f'   {wn[pt]:20s}', ' '.join(f'{int(t[0, it, i, pt] - t[0, it, i, pt - 1]):6d}' for i in range(7)))
     print('   step total          ', ' '.join(f'{int(t[0, it, i, 4] - t[0, it, i, 0]):6d}' for i in range(7)))
-fn = ['(arrive)', 'barrier passed', 'dq products', 'dq stored', 'vmcnt(13)', 'finish tile', 'dma issued']
+fn = ['(arrive)', 'barrier passed', 'dq products', 'vmcnt(13)', 'requests issued', 'dq tile staged', '-']
 print('wave 7')
 for it in (1, 2):
     print(f' item {it}: wait at T {t[1, it, 7, 0] - t[1, it - 1, 6, 6]} (from the last request of the item before), K^T fragments {t[1, it, 7, 1] - t[1, it, 7, 0]}')

@@ -987,29 +987,42 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
     // a DMA it knows of is in flight, which would park this wave -- and with it every barrier -- on what it has just issued.
     typedef __attribute__((address_space(3))) char lds_char;
     FragOff ffo = make_frag_off(lane);
-    // Row addresses in closed form: row r = 8 G + lane / 8 of a sequence sits at p1 + G * inc8 except row 0 (p0) and the
-    // clamped rows beyond L - 1 (plast); the chunk swizzle of the destination row only depends on the parity of G.
-    struct Src { const bf16raw* p1; const bf16raw* p0; const bf16raw* plast; long inc8; };
+    // Requests without vector-ALU work: row r = 8 G + lane / 8 of a sequence sits r * rs bytes behind the sequence's (virtual) row
+    // 0 on the token line, so a request is `buffer_load_dwordx4 voff, desc, soff offen lds` with a per-lane constant voff (the
+    // lane's row of the first 8 + the source chunk that the destination swizzle asks for: it only depends on the parity of G), a
+    // scalar soff = 8 G rs and a per-(item, tensor) descriptor whose range ends behind row L - 1 (rows beyond it read as zeros: their
+    // lse is +huge).  Only the first 8 rows use per-lane pointers: the sequence's row 0 is not on the line.  (A 64-bit multiply-add
+    // per request: 1600 cycles for the 13 requests of a step; pointer increments: 850.)
+    struct Src { const bf16raw* p1; const bf16raw* p0; u32x4 desc; };
     const int rl8 = lane >> 3, pc = lane & 7;
     const int swz[2] = {(pc ^ sw_of(rl8)) << 3, (pc ^ sw_of(8 + rl8)) << 3};
+    const long tok = p.mode == VTX_ATTN_SPACE ? p.T : 1;          // rows between consecutive tokens of a sequence
     auto make_src = [&](const bf16raw* base, long ld, int col0, const RowLin& rl) {
       Src x;
       x.p1 = base + (rl.base + (long)rl8 * rl.stride) * ld + col0;
       x.p0 = base + rl.row0 * ld + col0;
-      x.plast = base + lin_row(rl, p.L - 1) * ld + col0;
-      x.inc8 = 8 * rl.stride * ld;
+      const unsigned long a = reinterpret_cast<unsigned long>(base + rl.base * ld + col0);
+      x.desc[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+      x.desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+      x.desc[2] = __builtin_amdgcn_readfirstlane((unsigned)((p.L - 1) * tok * ld * 2 + 128));
+      x.desc[3] = 0x00020000u;
       return x;
     };
-    auto dma_tile = [&](const Src& x, int t, bf16raw* dst) {
+    auto dma_tile = [&](const Src& x, long ld, int t, bf16raw* dst) {
+      const unsigned rs = (unsigned)(tok * ld * 2);               // bytes per token
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int G = 4 * t + g;
-        const bf16raw* src = x.p1 + G * x.inc8;
-        if (G == 0) src = rl8 == 0 ? x.p0 : src;
-        if (t == NT_ - 1) src = G * 8 + rl8 >= p.L ? x.plast : src;      // padded query rows: any finite values (their lse is +huge)
-        src += swz[g & 1];
         const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(dst + g * 512));
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+        if (G == 0) {
+          const bf16raw* src = (rl8 == 0 ? x.p0 : x.p1) + swz[0];
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+        } else {
+          const unsigned voff = (unsigned)rl8 * rs + 2u * (unsigned)swz[g & 1];
+          const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(8 * G) * rs);
+          asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(x.desc), "s"(soff), "s"(m0v)
+                       : "memory", "m0");
+        }
       }
     };
     Src sq, sd, so;
@@ -1021,9 +1034,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       slse = lse + ((long)s * p.H + h) * p.L;
     };
     auto dma_item_tile = [&](int t, bf16raw* ost, float* lsd) {
-      dma_tile(sq, t, Qs + t * MG_TILE);
-      dma_tile(sd, t, Os + t * MG_TILE);
-      dma_tile(so, t, ost);
+      dma_tile(sq, p.ld_qkv, t, Qs + t * MG_TILE);
+      dma_tile(sd, p.ld_dout, t, Os + t * MG_TILE);
+      dma_tile(so, p.ld_out, t, ost);
       const int row = t * 32 + (lane & 31);
       const float* src = slse + (row < p.L ? row : p.L - 1);
       const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(lsd + t * 32));
@@ -1069,9 +1082,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
         MG_STAMP(1, i, 0)
         mg_barrier();                               // A(i): the dS tiles of step i are in buffer i & 1; nobody reads ring tile i any more
         MG_STAMP(1, i, 1)
+        f32x16 acc[2];
+        zero16(acc[0]); zero16(acc[1]);
         if (!(VTX_STREAM_ABLATE & 4)) {
-          f32x16 acc[2];
-          zero16(acc[0]); zero16(acc[1]);
 #pragma unroll
           for (int kt = 0; kt < NT_; ++kt) {
             const char* t0 = xch + (kt * 2 + (i & 1)) * MG_SCR_BYTES + scr_r;
@@ -1085,7 +1098,18 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
               for (int n2 = 0; n2 < 2; ++n2) acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[kt][s2][n2], u.v, acc[n2], 0, 0, 0);
             }
           }
-          MG_STAMP(1, i, 2)
+        }
+        MG_STAMP(1, i, 2)
+        // the step's requests go out between the products and their conversion: the last matrix instructions drain meanwhile
+        if (!(VTX_STREAM_ABLATE & 1)) {
+          // the requests of step i - 2 are complete behind this wait (those of step i - 1 may be in flight); the barrier of the next
+          // step publishes that, and workers 0 .. 3 turn the tile into delta / lse * log2(e) behind it
+          asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+          MG_STAMP(1, i, 3)
+          if (more) dma_item_tile(i, stO + ((i - nn) & 3) * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
+          MG_STAMP(1, i, 4)
+        }
+        if (!(VTX_STREAM_ABLATE & 4)) {
           // dQ^T tile (lane & 31 = query row, registers = 64 columns) -> bf16 [32][64] staging tile, scaled
           bf16raw* dst = dqs0 + q2 * dqs_dist;
           const int row = lane & 31;
@@ -1101,16 +1125,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
             }
         }
         q2 ^= 1;
-        MG_STAMP(1, i, 3)
-        if (!(VTX_STREAM_ABLATE & 1)) {
-          // the requests of step i - 2 are complete behind this wait (those of step i - 1 may be in flight); the barrier of the next
-          // step publishes that, and workers 0 .. 3 turn the tile into delta / lse * log2(e) behind it
-          asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-          MG_STAMP(1, i, 4)
-          MG_STAMP(1, i, 5)
-          if (more) dma_item_tile(i, stO + ((i - nn) & 3) * MG_TILE, LD + (par ^ 1) * 2 * MG_LP);
-          MG_STAMP(1, i, 6)
-        }
+        MG_STAMP(1, i, 5)
+        MG_STAMP(1, i, 6)
       }
       nn = (nn + 1) & 3;
       if (!more) break;

@@ -16,7 +16,8 @@ OUT = os.path.join(PKG, 'libvtx.so')
 OBJ = os.path.join(HERE, '_obj')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 SOURCES = ['api.hip', 'ln.hip', 'gemm_nt.hip', 'gemm_tn.hip', 'attn.hip', 'attn_mfma.hip', 'elementwise.hip', 'hog.hip', 'optim.hip', 'head.hip', 'mvit.hip', 'wprod.hip', 'xattn_mfma.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result', '-Wno-unused-value']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result', '-Wno-unused-value', '-Wno-inline-asm',
+         '-Wno-cuda-compat']
 EXTRA = {'hog.hip': ['-ffp-contract=off']}       # bit-exact HOG: no fma contraction
 
 
