@@ -726,6 +726,43 @@ def test_attention_mfma_matches_valu(S, L, vtx_opts):
 
 @pytest.mark.parametrize('mode,S,L,H', [('contig', 3, 197, 3), ('contig', 2, 224, 2), ('contig', 1, 193, 1), ('contig', 70, 197, 12),
                                         ('space', 0, 197, 3), ('space', 0, 211, 12)])
+def test_attention_forward_streamed_equals_workgroup_per_item(mode, S, L, H, vtx_opts):
+    """attn_fwd_stream=1 (193..224 tokens): one persistent workgroup per CU, a wave per query tile, K / V of the next item brought
+    in by LDS-DMA while the current one is computed.  The tile body is the other kernel's: outputs and lse bit-identical; 840 items =
+    several per workgroup (double buffer, padded key rows zero-filled by the range check)."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG, ATTN_SPACE
+    hd = 64
+    D = H * hd
+    bf = torch.bfloat16
+    if mode == 'contig':
+        qkv = dev(rnd(S, L, 3 * D, seed=L) * 1.5, bf)
+        args = (ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        new_out = lambda: torch.full((S, L, D), float('nan'), dtype=bf, device=DEV)       # noqa: E731
+        nlse = S * H * L
+    else:
+        B, T, P = (2, 3, L - 1) if H == 3 else (6, 8, L - 1)
+        N = P * T
+        qkv = dev(rnd(B, 1 + N, 3 * D, seed=L) * 1.5, bf)
+        args = (ATTN_SPACE, B * T, L, H, hd, hd ** -0.5, B, T, P)
+        new_out = lambda: torch.full((B * N + B * T, D), float('nan'), dtype=bf, device=DEV)   # noqa: E731
+        nlse = B * T * H * L
+    res = []
+    for st in ('0', '1', '1'):
+        vtx_opts('attn_fwd_stream', st)
+        o = new_out()
+        lse = torch.full((nlse,), float('nan'), device=DEV)
+        ops.attn_fwd(qkv, o, lse, *args)
+        torch.cuda.synchronize()
+        res.append((o, lse))
+    assert torch.isfinite(res[0][0].float()).all() and torch.isfinite(res[0][1]).all()
+    for o, lse in res[1:]:
+        assert torch.equal(o, res[0][0])
+        assert torch.equal(lse, res[0][1])
+
+
+@pytest.mark.parametrize('mode,S,L,H', [('contig', 3, 197, 3), ('contig', 2, 224, 2), ('contig', 1, 193, 1), ('contig', 70, 197, 12),
+                                        ('space', 0, 197, 3), ('space', 0, 211, 12)])
 def test_attention_backward_streamed_one_phase(mode, S, L, H, vtx_opts):
     """attn_fused=2 (193..224 tokens): one phase per (sequence, head) -- a wave owns a key tile, dS goes through LDS once for
     the dq product, the seven partial dq tiles are summed in fixed order.  dk / dv: the same products in the same order as the

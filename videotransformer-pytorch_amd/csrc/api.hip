@@ -46,6 +46,7 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "attn_hw_fwd") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.attn_hw_fwd = g; return VTX_OK; }
   if (strcmp(name, "attn_hw_bwd") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.attn_hw_bwd = g; return VTX_OK; }
   if (strcmp(name, "attn_fused") == 0) { const int v = atoi(value); o.attn_fused = v < 0 ? 0 : v > 2 ? 2 : v; return VTX_OK; }
+  if (strcmp(name, "attn_fwd_stream") == 0) { o.attn_fwd_stream = atoi(value) != 0; return VTX_OK; }
   if (strcmp(name, "attn_dkv") == 0) { const int g = atoi(value); if (g < 0 || g > 4) return VTX_EINVAL; o.attn_dkv = g; return VTX_OK; }
   if (strcmp(name, "pp_grid") == 0) { const int g = atoi(value); if (g < 8 || g > 4096 || g % 8) return VTX_EINVAL; o.pp_grid = g; return VTX_OK; }
   if (strcmp(name, "pp_cg") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.pp_cg = g; return VTX_OK; }
@@ -62,7 +63,7 @@ Options& options() {
     static const char* const env[][2] = {{"VTX_GEMM_NT", "gemm_nt"}, {"VTX_GEMM_TN", "gemm_tn"}, {"VTX_GEMM_NODMA", "gemm_nodma"},
                                          {"VTX_TN_SAFE", "tn_safe"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
                                          {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"},
-                                         {"VTX_GEMM_PP_CONT", "pp_cont"}, {"VTX_LN_ROWS", "ln_rows"}, {"VTX_ATTN_HW_FWD", "attn_hw_fwd"}, {"VTX_ATTN_HW_BWD", "attn_hw_bwd"}, {"VTX_ATTN_DKV", "attn_dkv"},
+                                         {"VTX_GEMM_PP_CONT", "pp_cont"}, {"VTX_LN_ROWS", "ln_rows"}, {"VTX_ATTN_HW_FWD", "attn_hw_fwd"}, {"VTX_ATTN_HW_BWD", "attn_hw_bwd"}, {"VTX_ATTN_DKV", "attn_dkv"}, {"VTX_ATTN_FWD_STREAM", "attn_fwd_stream"},
                                          {"VTX_ATTN_FUSED", "attn_fused"}};
     for (const auto& e : env) {
       const char* v = getenv(e[0]);

@@ -1325,6 +1325,185 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
   store_dq(6, false);
 }
 
+// ------------------------------------------------------------------- forward with streamed K / V (round 4, option attn_fwd_stream)
+// The forward kernel at the top of this file is a workgroup per (sequence, head): fetch K and V (global -> registers -> LDS),
+// barrier, seven query tiles on four waves (2 + 2 + 2 + 1), stores -- load, compute and store phases of a workgroup follow each
+// other and only the second workgroup of the CU covers them.  Here one workgroup per CU is persistent over the items like the
+// backward kernel above: waves 0 .. 6 own one query tile each (the tile body of the kernel above, unchanged: bit-identical
+// results), wave 7 brings the NEXT item's K and V tiles into the other half of a double buffer by LDS-DMA (56 requests, range-
+// checked buffer loads: padded key rows read as zeros) while the workers run; one barrier per item.
+constexpr size_t MGF_LDS_BYTES = (size_t)2 * 2 * 7 * MG_TILE * 2 + 8 * MA_STAGE_ELEMS * 2;
+
+template <int NT_>
+__global__ __launch_bounds__(MF_THREADS, 1) void attn_fwd_stream_mfma_kernel(AttnP p, const bf16raw* __restrict__ qkv,
+                                                                          bf16raw* __restrict__ out, float* __restrict__ lse) {
+  static_assert(NT_ == 7, "seven 32-row tiles (193 .. 224 tokens)");
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int D = p.H * 64, items = p.S * p.H;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  bf16raw* KV = reinterpret_cast<bf16raw*>(sm_raw);               // [buffer][K | V][7 tiles][32][64]
+  bf16raw* stg = KV + 2 * 2 * NT_ * MG_TILE + wave * MA_STAGE_ELEMS;
+  const int stride = gridDim.x;
+  if (blockIdx.x >= items) return;
+  const float invH = 1.0f / (float)p.H, invT = p.mode == VTX_ATTN_SPACE ? 1.0f / (float)p.T : 1.0f;
+
+  if (wave == MF_LOADER) {                          // ------------------------------------------------------------- wave 7
+    typedef __attribute__((address_space(3))) char lds_char;
+    const int rl8 = lane >> 3, pc = lane & 7;
+    const int swz[2] = {(pc ^ sw_of(rl8)) << 3, (pc ^ sw_of(8 + rl8)) << 3};
+    const long tok = p.mode == VTX_ATTN_SPACE ? p.T : 1;
+    const unsigned rs = (unsigned)(tok * p.ld_qkv * 2);           // bytes per token
+    const unsigned voff[2] = {(unsigned)rl8 * rs + 2u * (unsigned)swz[0], (unsigned)rl8 * rs + 2u * (unsigned)swz[1]};
+    auto request = [&](int item, int buf) {
+      const int s = mg_div(item, p.H, invH), h = item - s * p.H;
+      const RowLin li = mg_lin_in(p, s, invT);
+#pragma unroll
+      for (int kv = 0; kv < 2; ++kv) {
+        const int col0 = (1 + kv) * D + h * 64;
+        const bf16raw* p1 = qkv + (li.base + (long)rl8 * li.stride) * p.ld_qkv + col0;
+        const bf16raw* p0 = qkv + li.row0 * p.ld_qkv + col0;
+        const unsigned long a = reinterpret_cast<unsigned long>(qkv + li.base * p.ld_qkv + col0);
+        u32x4 desc;
+        desc[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        desc[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+        desc[2] = __builtin_amdgcn_readfirstlane((unsigned)((p.L - 1) * tok * p.ld_qkv * 2 + 128));
+        desc[3] = 0x00020000u;
+        bf16raw* dst = KV + (buf * 2 + kv) * NT_ * MG_TILE;
+#pragma unroll
+        for (int G = 0; G < 4 * NT_; ++G) {
+          const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_char*)(dst + G * 512));
+          if (G == 0) {
+            const bf16raw* src = (rl8 == 0 ? p0 : p1) + swz[0];
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+          } else {
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(8 * G) * rs);
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff[G & 1]), "s"(desc), "s"(soff), "s"(m0v)
+                         : "memory", "m0");
+          }
+        }
+      }
+    };
+    int item = blockIdx.x, buf = 0;
+    request(item, 0);
+    while (true) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      mg_barrier();                                 // E: K / V of `item` are in buffer `buf`; the workers are done with the other buffer
+      const int next = item + stride;
+      if (next >= items) break;
+      request(next, buf ^ 1);
+      item = next;
+      buf ^= 1;
+    }
+    mg_barrier();                                   // the workers' last item
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------------------- workers
+  const float c2 = p.scale * LOG2E;
+  const int ragged = (p.L & 31) ? NT_ - 1 : -1;    // the key tile that holds padded keys
+  const FragOff fo0 = make_frag_off(lane);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int item = blockIdx.x, buf = 0;
+  int s = mg_div(item, p.H, invH), h = item - s * p.H;
+  RowLin li = mg_lin_in(p, s, invT);
+  const int q = wave * 32 + (lane & 31);
+  bf16x8 qf[4];
+  load_row_frags(qf, qkv, p.ld_qkv, h * 64, li, q, p.L, lane);
+  while (true) {
+    mg_barrier();                                   // E
+    FragOff fo = fo0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.rows[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fo.cols[i >> 1][i & 1]));
+    const bf16raw* Ks = KV + buf * 2 * NT_ * MG_TILE;
+    const bf16raw* Vs = Ks + NT_ * MG_TILE;
+    const int next = item + stride;
+    const bool more = next < items;
+    const int nx = more ? next : item;
+    const int sn = mg_div(nx, p.H, invH), hn = nx - sn * p.H;
+    const RowLin lin = mg_lin_in(p, sn, invT);
+    bf16x8 qn[4];                                   // the next item's query rows, in flight during this one
+    load_row_frags(qn, qkv, p.ld_qkv, hn * 64, lin, q, p.L, lane);
+    f32x16 acc[2];
+    zero16(acc[0]);
+    zero16(acc[1]);
+    float m = -1e30f, l = 0.f;                      // running max of the RAW scores (scale > 0)
+#pragma unroll
+    for (int kb = 0; kb < NT_; kb += MA_KB) {
+      f32x16 st[MA_KB];
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t) {
+        if (kb + t < NT_) {
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, (kb + t) * 32, 0, fo), qf[0], zero, 0, 0, 0);
+#pragma unroll
+          for (int ks = 1; ks < 4; ++ks)
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_o(Ks, (kb + t) * 32, ks, fo), qf[ks], st[t], 0, 0, 0);
+        }
+      }
+      float bm = -1e30f;
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t)
+        if (kb + t < NT_) {
+          if (kb + t == ragged) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((kb + t) * 32 + crow(r, lane) >= p.L) st[t][r] = -1e30f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bm = fmaxf(bm, st[t][r]);
+        }
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m, bm);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+      m = mn;
+      const float mc = mn * c2;
+      float bl = 0.f;
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t)
+        if (kb + t < NT_) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -mc)); st[t][r] = e; bl += e; }
+        }
+      bl += __shfl_xor(bl, 32, 64);
+      l = l * alpha + bl;
+      if (kb > 0) {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[n2][r] *= alpha;
+      }
+#pragma unroll
+      for (int t = 0; t < MA_KB; ++t)
+        if (kb + t < NT_) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            float pf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = st[t][8 * s2 + j];
+            const bf16x8 pb = pack8(pf);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+              acc[n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_o(Vs, (kb + t) * 32 + 16 * s2, n2, fo), pb, acc[n2], 0, 0, 0);
+          }
+        }
+    }
+    {
+      const RowLin lo = mg_lin_out(p, s, invT);
+      const long orow = wave * 32 + (lane >> 3);
+      bf16raw* p_lin = out + (lo.base + orow * lo.stride) * p.ld_out + h * 64;
+      bf16raw* p_row0 = wave == 0 ? out + lo.row0 * p.ld_out + h * 64 : p_lin;
+      mg_store_rows_lin(stg, acc, 1.0f / l, lane, p_lin, 8 * lo.stride * p.ld_out, p_row0, p.L - wave * 32);
+      if (q < p.L && lane < 32) lse[((long)s * p.H + h) * p.L + q] = (m * c2) * LN2 + __logf(l);
+    }
+    if (!more) break;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    item = next; s = sn; h = hn; li = lin; buf ^= 1;
+  }
+  mg_barrier();
+}
+
 // =====================================================================================
 // Short sequences (L <= 32, contiguous rows): temporal attention of the divided block
 // (L = T = 8) and ViViT's temporal encoder (L = 9).  G = 32/L sequences are packed into one
@@ -1591,6 +1770,13 @@ static void allow_lds(size_t lds) {
 
 int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
   const int nt = (p.L + 31) >> 5, Lp = nt * 32;
+  if (nt == 7 && options().attn_fwd_stream) {      // one persistent workgroup per CU, K / V of the next item streamed in by LDS-DMA
+    allow_lds<attn_fwd_stream_mfma_kernel<7>>(MGF_LDS_BYTES);
+    const int items = p.S * p.H, cus = device_cus();
+    hipLaunchKernelGGL(attn_fwd_stream_mfma_kernel<7>, dim3(items < cus ? items : cus), dim3(MF_THREADS), MGF_LDS_BYTES, st, p,
+                       (const bf16raw*)qkv, (bf16raw*)out, lse);
+    return check_launch("attn_fwd_stream_mfma");
+  }
   const size_t lds = (size_t)2 * Lp * 64 * 2 + 4 * MA_STAGE_ELEMS * 2;
   if (nt == 7) {                                   // L in 193 .. 224: the 197 tokens of every 224^2 / patch 16 model
     allow_lds<attn_fwd_mfma_kernel<7>>(lds);

@@ -174,6 +174,7 @@ struct Options {
   int attn_hw_bwd = 0;       //   (0: one head per workgroup, four row tiles)
   int attn_fused = 2;        // VTX_ATTN_FUSED: backward of the 33..224-token attention: 2 = one phase per (sequence, head), operands streamed (193..224
                              // tokens; other lengths as 1), 1 = one kernel with a dq and a dk / dv phase (one pass over HBM), 0 = dq + dkv kernels
+  int attn_fwd_stream = 1;   // VTX_ATTN_FWD_STREAM: forward of the 193..224-token attention as a persistent kernel with streamed K / V (bit-identical results)
   int attn_dkv = 3;          // VTX_ATTN_DKV: dk / dv kernel of the 197-token attention: 0 = run-time query-tile loop, 1..4 = unrolled variants
                              // (3 = unrolled, next key tile loaded behind the current one: profiles/round3_attn_dkv_variants.txt)
   int ln_rows = 3;           // VTX_LN_ROWS: rows per trip of the LayerNorm forward kernel (1 = one row per wave, the round-1 kernel; 2 .. 4: ln_fwd2_kernel)
