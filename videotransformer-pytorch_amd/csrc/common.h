@@ -171,7 +171,7 @@ struct Options {
   int tn_safe = 0;           // VTX_TN_SAFE: bounds-checked TN loader (diagnostic)
   int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
   int attn_hw_fwd = 16;      // VTX_ATTN_HW_FWD / _BWD: short-sequence attention with n heads of a row tile in one workgroup
-  int attn_hw_bwd = 0;       //   (0: one head per workgroup, four row tiles)
+  int attn_hw_bwd = 4;       //   (0: one head per workgroup, four row tiles; backward: 4 heads -- 512 contiguous bytes per row -- measured best)
   int attn_fused = 2;        // VTX_ATTN_FUSED: backward of the 33..224-token attention: 2 = one phase per (sequence, head), operands streamed (193..224
                              // tokens; other lengths as 1), 1 = one kernel with a dq and a dk / dv phase (one pass over HBM), 0 = dq + dkv kernels
   int attn_fwd_stream = 1;   // VTX_ATTN_FWD_STREAM: forward of the 193..224-token attention as a persistent kernel with streamed K / V (bit-identical results)
