@@ -829,7 +829,7 @@ constexpr int MG_TILE = 32 * 64;                // elements of one [32][64] bf16
 constexpr int MG_SCR_LD = 36;                   // a dS tile in the exchange area: [32 keys][36] bf16 (72-byte rows: conflict-free 8-byte stores)
 constexpr int MG_SCR_BYTES = 32 * MG_SCR_LD * 2;             // 2304
 constexpr int MG_XCH_BYTES = 7 * 2 * MG_SCR_BYTES;           // [worker][buffer][2304]: a worker's two buffers also hold its V tile (4 KB) at the top of an item
-constexpr size_t MG_LDS_BYTES = (size_t)2 * 7 * MG_TILE * 2 + MG_XCH_BYTES + 8 * MA_STAGE_ELEMS * 2 + 2 * 2 * MG_LP * 4 + 4 * MG_TILE * 2 + MG_TILE * 2;
+constexpr size_t MG_LDS_BYTES = (size_t)2 * 7 * MG_TILE * 2 + MG_XCH_BYTES + 8 * MA_STAGE_ELEMS * 2 + 2 * 2 * MG_LP * 4 + 4 * MG_TILE * 2 + 2 * 32 * 64 * 4;
 
 __device__ inline void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // n / d for 0 <= n < 2^24 with inv = 1.0f / d (an integer division is ~40 vector instructions; the item -> (sequence, head) and
@@ -968,12 +968,12 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
       lp[MG_LP] = row < p.L ? dl : 0.f;
     }
   };
-  // dq tiles leave wave 7 as bf16 in one of two staging tiles (its own and one more; by the parity of the running step count) and
-  // are stored by workers 0 .. 3 two steps later, 8 whole rows each: wave 7 is the busiest wave of a step
-  // (second tile addressed as first + parity * distance: indexing an array of two pointers makes the access a FLAT one, and a FLAT
-  // load waits for vmcnt(0))
-  bf16raw* dqs0 = stg0 + MF_LOADER * MA_STAGE_ELEMS;
-  constexpr int dqs_dist = (8 - MF_LOADER) * MA_STAGE_ELEMS + (2 * 2 * MG_LP * 4 + 4 * MG_TILE * 2) / 2;   // elements from tile 0 to tile 1
+  // dq tiles leave wave 7 as fp32 [32 queries][64] in one of two LDS tiles (by the parity of the running step count; 16-byte chunk
+  // index XOR-ed with the query's low bits: conflict-free 16-byte writes by query-per-lane and reads by row) and are scaled, rounded
+  // and stored by workers 0 .. 3 two steps later, 8 whole rows each: wave 7 is the busiest wave of a step, the conversion (48 vector
+  // instructions) costs it ~500 cycles
+  char* dqf = reinterpret_cast<char*>(LD) + 2 * 2 * MG_LP * 4 + 4 * MG_TILE * 2;
+  constexpr int dqf_bytes = 32 * 64 * 4;
 
   if (wave == MF_LOADER) {                          // ------------------------------------------------- wave 7: feeds, and owns dq
     // Everything this wave brings in travels HBM -> LDS by LDS-DMA (no registers, any number of requests in flight): the
@@ -1110,18 +1110,16 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
           MG_STAMP(1, i, 4)
         }
         if (!(VTX_STREAM_ABLATE & 4)) {
-          // dQ^T tile (lane & 31 = query row, registers = 64 columns) -> bf16 [32][64] staging tile, scaled
-          bf16raw* dst = dqs0 + q2 * dqs_dist;
-          const int row = lane & 31;
+          // dQ^T tile (lane & 31 = query row, registers = 64 columns) -> fp32 tile
+          char* dst = dqf + q2 * dqf_bytes + (lane & 31) * 256;
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const int col = nt * 32 + 8 * g + 4 * (lane >> 5);
-              union { bf16x4 v; uint2 u; } w;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) w.v[j] = (__bf16)(acc[nt][4 * g + j] * p.scale);
-              *reinterpret_cast<uint2*>(dst + sw_off(row, col)) = w.u;
+              const int ch = nt * 8 + 2 * g + (lane >> 5);
+              float4 v;
+              v.x = acc[nt][4 * g]; v.y = acc[nt][4 * g + 1]; v.z = acc[nt][4 * g + 2]; v.w = acc[nt][4 * g + 3];
+              *reinterpret_cast<float4*>(dst + ((ch ^ (lane & 15)) << 4)) = v;
             }
         }
         q2 ^= 1;
@@ -1172,7 +1170,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void attn_bwd_stream_mfma_kernel(Att
   auto store_dq = [&](int t, bool prev) {           // workers 0 .. 3: 8 rows each of query tile t (of the previous item: prev)
     if (!(VTX_STREAM_ABLATE & 4)) {                 // (no branch around the LDS read: it is scheduled into the step's other work)
       const int r = (wave & 3) * 8 + (lane >> 3), c = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(dqs0 + rp * dqs_dist + r * 64 + ((c ^ sw_of(r)) << 3));
+      const char* src = dqf + rp * dqf_bytes + r * 256;
+      const float4 a = *reinterpret_cast<const float4*>(src + (((2 * c) ^ (r & 15)) << 4));
+      const float4 b = *reinterpret_cast<const float4*>(src + (((2 * c + 1) ^ (r & 15)) << 4));
+      union { bf16x8 v8; uint4 u; } w;
+      w.v8[0] = (__bf16)(a.x * p.scale); w.v8[1] = (__bf16)(a.y * p.scale); w.v8[2] = (__bf16)(a.z * p.scale); w.v8[3] = (__bf16)(a.w * p.scale);
+      w.v8[4] = (__bf16)(b.x * p.scale); w.v8[5] = (__bf16)(b.y * p.scale); w.v8[6] = (__bf16)(b.z * p.scale); w.v8[7] = (__bf16)(b.w * p.scale);
+      const uint4 v = w.u;
       bf16raw* lin = prev ? dq_lin_prev : dq_lin;
       bf16raw* dst = lin + (4 * t + (wave & 3)) * (prev ? dq_step8_prev : dq_step8);
       if (t == 0 && r == 0) dst = prev ? dq_row0_prev : dq_row0;
