@@ -514,7 +514,7 @@ def main():
                                        'ms_per_step': round(tot['gemm_tn'][1] / nb, 3)}
             hbm = []
             label = {'ln_fwd': 'ln_fwd_kernel', 'ln_bwd': 'ln_bwd_kernel', 'attn_fwd_time': 'attn_fwd_small_kernel (temporal, T tokens)',
-                     'attn_bwd_time': 'attn_bwd_small_kernel (temporal)', 'attn_fwd_space': 'attn_fwd_mfma_kernel (spatial, 197 tokens)',
+                     'attn_bwd_time': 'attn_bwd_small_kernel (temporal)', 'attn_fwd_space': 'attn_fwd_*_mfma_kernel (spatial, 197 tokens)',
                      'attn_bwd_space': 'attn_bwd_*_mfma_kernel (spatial)', 'patch_rows': 'patch_rows_kernel (clip gather)',
                      'colsum': 'colsum_kernel', 'hog': 'hog_kernel (1024 frames 224x224x3 uint8 -> float64 features)'}
             for c, (cn, cms, cfl, cby) in tot.items():
