@@ -12,16 +12,16 @@
 //     y[i] (+)= alpha_y * sum_k A(i,k) x[k] + beta_z * z[i].
 //
 // 64 x 64 output tile per 512-thread workgroup: 8 waves = 4 quadrants of 32 x 32 (v_mfma_f32_32x32x2_f32, an fp32 fma
-// chain) x 2 halves of every 32-deep K tile, folded through LDS in a fixed order (deterministic).  768^3: 144
+// chain) x 2 halves of every 64-deep K tile, folded through LDS in a fixed order (deterministic).  768^3: 144
 // workgroups, 192 matrix instructions of 64 cycles per wave = 12.3k cycles; operands are L2-resident (2.4 MB each).
-// LDS tiles are k-major [32][65]: fragment reads are 32 consecutive words per lane group, and both store patterns
+// LDS tiles are k-major [64][65]: fragment reads are 32 consecutive words per lane group, and both store patterns
 // (vector along k / vector along i) are bank-conflict free with the odd row stride.
 // Algorithmic work per launch: 2*N1*N2*K flop, (N1*K + K*N2 + N1*N2) * 4 bytes.
 #include "common.h"
 
 namespace vtx {
 
-constexpr int WP_T = 64, WP_BK = 32, WP_LD = 65, WP_THREADS = 512;
+constexpr int WP_T = 64, WP_BK = 64, WP_LD = 65, WP_THREADS = 512, WP_V = WP_T * WP_BK / 4 / WP_THREADS;   // float4 per thread, operand and K tile
 
 struct WprodParams {
   int N1, N2, K;
@@ -43,37 +43,48 @@ __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
   const int i0 = blockIdx.y * WP_T, j0 = blockIdx.x * WP_T;
   const bool with_y = p.y != nullptr && blockIdx.x == 0;
 
-  // loader coordinates: (o = index along the other axis, c = first of 4 elements along the contiguous axis)
-  const int ak = A_KCONT ? (tid & 7) * 4 : tid >> 4, ai = A_KCONT ? tid >> 3 : (tid & 15) * 4;
-  const int bk = B_KCONT ? (tid & 7) * 4 : tid >> 4, bj = B_KCONT ? tid >> 3 : (tid & 15) * 4;
-  // Operand tiles are L2-resident but an L2 round trip (~1 us under load) is four times the 8 matrix instructions of a
+  // loader coordinates of float4 v of this thread (index tid + v * 512 of the tile's 1024): k-contiguous operands are cut into
+  // float4 along k (16 per row of the other axis), the others along i / j (16 per k)
+  auto a_k = [&](int v) { const int id = tid + v * WP_THREADS; return A_KCONT ? (id & 15) * 4 : id >> 4; };
+  auto a_i = [&](int v) { const int id = tid + v * WP_THREADS; return A_KCONT ? id >> 4 : (id & 15) * 4; };
+  auto b_k = [&](int v) { const int id = tid + v * WP_THREADS; return B_KCONT ? (id & 15) * 4 : id >> 4; };
+  auto b_j = [&](int v) { const int id = tid + v * WP_THREADS; return B_KCONT ? id >> 4 : (id & 15) * 4; };
+  // Operand tiles are L2-resident but an L2 round trip (~1 us under load) is several times the matrix instructions of a
   // K tile: three K tiles of register prefetch keep the loop on the matrix pipe instead of on that latency
-  // (one tile of look-ahead measured 45 us per 768^3 product, latency-bound).
+  // (one tile of look-ahead measured 45 us per 768^3 product, latency-bound).  64-deep K tiles (round 4; 32 before): half as many
+  // barrier-separated iterations, each of which is bound by its latency chain, not by its 16 matrix instructions.
   constexpr int PF = 3;
-  float4 ra[PF], rb[PF];
+  float4 ra[PF][WP_V], rb[PF][WP_V];
   float rx[PF] = {0.f, 0.f, 0.f};
-  auto gload = [&](int k0, float4& va, float4& vb, float& vx) {
-    {
-      const int i = i0 + ai, k = k0 + ak;
-      const bool ok = i < p.N1 && k < p.K;           // extents are multiples of 4: a vector is inside or outside as a whole
-      const float* src = p.A + (ok ? (long)i * p.a_rs + (long)k * p.a_ks : 0L);
-      va = *reinterpret_cast<const float4*>(src);
-      if (!ok) va = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {
-      const int j = j0 + bj, k = k0 + bk;
-      const bool ok = j < p.N2 && k < p.K;
-      const float* src = p.B + (ok ? (long)k * p.b_ks + (long)j * p.b_cs : 0L);
-      vb = *reinterpret_cast<const float4*>(src);
-      if (!ok) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto gload = [&](int k0, float4 (&va)[WP_V], float4 (&vb)[WP_V], float& vx) {
+#pragma unroll
+    for (int v = 0; v < WP_V; ++v) {
+      {
+        const int i = i0 + a_i(v), k = k0 + a_k(v);
+        const bool ok = i < p.N1 && k < p.K;         // extents are multiples of 4: a vector is inside or outside as a whole
+        const float* src = p.A + (ok ? (long)i * p.a_rs + (long)k * p.a_ks : 0L);
+        va[v] = *reinterpret_cast<const float4*>(src);
+        if (!ok) va[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      {
+        const int j = j0 + b_j(v), k = k0 + b_k(v);
+        const bool ok = j < p.N2 && k < p.K;
+        const float* src = p.B + (ok ? (long)k * p.b_ks + (long)j * p.b_cs : 0L);
+        vb[v] = *reinterpret_cast<const float4*>(src);
+        if (!ok) vb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     if (with_y && tid < WP_BK) vx = (k0 + tid) < p.K ? p.x[k0 + tid] : 0.f;
   };
-  auto lstore = [&](int buf, const float4& va, const float4& vb, float vx) {
-    if (A_KCONT) { As[buf][ak][ai] = va.x; As[buf][ak + 1][ai] = va.y; As[buf][ak + 2][ai] = va.z; As[buf][ak + 3][ai] = va.w; }
-    else { As[buf][ak][ai] = va.x; As[buf][ak][ai + 1] = va.y; As[buf][ak][ai + 2] = va.z; As[buf][ak][ai + 3] = va.w; }
-    if (B_KCONT) { Bs[buf][bk][bj] = vb.x; Bs[buf][bk + 1][bj] = vb.y; Bs[buf][bk + 2][bj] = vb.z; Bs[buf][bk + 3][bj] = vb.w; }
-    else { Bs[buf][bk][bj] = vb.x; Bs[buf][bk][bj + 1] = vb.y; Bs[buf][bk][bj + 2] = vb.z; Bs[buf][bk][bj + 3] = vb.w; }
+  auto lstore = [&](int buf, const float4 (&va)[WP_V], const float4 (&vb)[WP_V], float vx) {
+#pragma unroll
+    for (int v = 0; v < WP_V; ++v) {
+      const int ak = a_k(v), ai = a_i(v), bk = b_k(v), bj = b_j(v);
+      if (A_KCONT) { As[buf][ak][ai] = va[v].x; As[buf][ak + 1][ai] = va[v].y; As[buf][ak + 2][ai] = va[v].z; As[buf][ak + 3][ai] = va[v].w; }
+      else { As[buf][ak][ai] = va[v].x; As[buf][ak][ai + 1] = va[v].y; As[buf][ak][ai + 2] = va[v].z; As[buf][ak][ai + 3] = va[v].w; }
+      if (B_KCONT) { Bs[buf][bk][bj] = vb[v].x; Bs[buf][bk + 1][bj] = vb[v].y; Bs[buf][bk + 2][bj] = vb[v].z; Bs[buf][bk + 3][bj] = vb[v].w; }
+      else { Bs[buf][bk][bj] = vb[v].x; Bs[buf][bk][bj + 1] = vb[v].y; Bs[buf][bk][bj + 2] = vb[v].z; Bs[buf][bk][bj + 3] = vb[v].w; }
+    }
     if (with_y && tid < WP_BK) xs[buf][tid] = vx;
   };
 
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float yacc = 0.f;
-  const int fa = qi * 32 + (lane & 31), fb = qj * 32 + (lane & 31), fk = h * 16 + (lane >> 5);
+  const int fa = qi * 32 + (lane & 31), fb = qj * 32 + (lane & 31), fk = h * (WP_BK / 2) + (lane >> 5);
   const int nk = (p.K + WP_BK - 1) / WP_BK;
   // register slot of K tile t = t % PF; LDS buffer = t & 1.  Tile t is consumed while tiles t+1 .. t+PF are in flight.
 #pragma unroll
@@ -90,10 +101,10 @@ __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
   lstore(0, ra[0], rb[0], rx[0]);
   if (PF < nk) gload(PF * WP_BK, ra[0], rb[0], rx[0]);
   __syncthreads();
-  auto ktile = [&](int kt, float4& va, float4& vb, float& vx) {   // va/vb/vx: the slot that holds tile kt + 1
+  auto ktile = [&](int kt, float4 (&va)[WP_V], float4 (&vb)[WP_V], float& vx) {   // va/vb/vx: the slot that holds tile kt + 1
     const int buf = kt & 1;
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < WP_BK / 4; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][fk + 2 * s][fa], Bs[buf][fk + 2 * s][fb], acc, 0, 0, 0);
     if (with_y && wave == 0) {                        // rows i0 .. i0+63 of A times x, k ascending: lane = row
 #pragma unroll
