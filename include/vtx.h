@@ -63,15 +63,19 @@ const char* vtx_last_error_string(void);
 /* Tuning / diagnostic switches (process-wide; initial values from the VTX_* environment variables,
  * read once): "gemm_nt" = auto|pp256|dma2|ring128x3|ring128x4k32|ring256x3|ring256x3k32|ring256x4k32,
  * "gemm_tn" = auto|pp256|ring|dma2, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "attn_hw_fwd", "attn_hw_bwd" = n
- * (short-sequence attention: n heads of a row tile per workgroup, 0 = one head and four row tiles), "pp_grid", "pp_cg",
+ * (short-sequence attention: n heads of a row tile per workgroup, 0 = one head and four row tiles; defaults 16 / 4), "pp_grid", "pp_cg",
  * "pp_epi" = integers ("pp_epi": 1 = per-pass epilogue of the persistent GEMM; 2 / 3 = timing diagnostics that skip
  * its stores / its LDS staging and produce WRONG output; 4 = the general passes instead of the lean ones of the
  * continuous-flow kernels, 5 = lean passes (the default, same as 0), 6 = lean passes with the first four of every tile rolled
  * into its last K tile -- 4 / 5 / 6 give identical results), "pp_cont" = 0|1 (continuous flow of the persistent GEMM: the
  * next tile's first K tiles are requested inside the current main loop; 1 by default, 0 = per-tile prologue; identical
  * results), "ln_rows" = 1 .. 4 (rows per trip of the LayerNorm forward kernel, default 3; identical results),
- * "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py).  Returns VTX_EINVAL for an unknown
- * name or value. */
+ * "attn_fused" = 0|1|2 (backward of the 33..224-token attention: kernel pair / one pass with two phases / one phase with streamed
+ * operands (193..224 tokens; default); dk and dv identical, dq of 2 equal to fp32 rounding), "attn_fwd_stream" = 0|1 (forward of
+ * the 193..224-token attention: workgroup per (sequence, head) / persistent with streamed K and V (default); identical results),
+ * "attn_dkv" = 0 .. 4 (variants of the pair's dk / dv kernel; identical results),
+ * "pp_trace" = device address of a timeline buffer (tools/pp_timeline.py, tools/attn_timeline.py).  Returns VTX_EINVAL for an
+ * unknown name or value. */
 int vtx_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------ LayerNorm
