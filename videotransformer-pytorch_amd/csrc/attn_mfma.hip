@@ -1782,7 +1782,8 @@ static void allow_lds(size_t lds) {
 
 int attn_fwd_mfma_launch(const AttnP& p, const void* qkv, void* out, float* lse, hipStream_t st) {
   const int nt = (p.L + 31) >> 5, Lp = nt * 32;
-  if (nt == 7 && options().attn_fwd_stream) {      // one persistent workgroup per CU, K / V of the next item streamed in by LDS-DMA
+  // (mg_div splits item -> (sequence, head) -> (clip, frame) with reciprocal multiplies that are exact below 2^24 items)
+  if (nt == 7 && options().attn_fwd_stream && (long)p.S * p.H < (1L << 24)) {      // one persistent workgroup per CU, K / V of the next item streamed in by LDS-DMA
     allow_lds<attn_fwd_stream_mfma_kernel<7>>(MGF_LDS_BYTES);
     const int items = p.S * p.H, cus = device_cus();
     hipLaunchKernelGGL(attn_fwd_stream_mfma_kernel<7>, dim3(items < cus ? items : cus), dim3(MF_THREADS), MGF_LDS_BYTES, st, p,
@@ -1841,7 +1842,7 @@ static int attn_bwd_stream_launch(const AttnP& p, const void* qkv, const void* o
 int attn_bwd_mfma_launch(const AttnP& p, const void* qkv, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, void* dqkv_cls, hipStream_t st) {
   const int nt = (p.L + 31) >> 5;
-  if (options().attn_fused >= 2 && nt == 7) return attn_bwd_stream_launch(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
+  if (options().attn_fused >= 2 && nt == 7 && (long)p.S * p.H < (1L << 24)) return attn_bwd_stream_launch(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
   if (options().attn_fused && nt <= 7) {           // one pass over HBM: all four operand tiles fit the LDS of one workgroup
     if (nt == 7) return attn_bwd_fused_launch_t<7>(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
     return attn_bwd_fused_launch_t<0>(p, qkv, o, dout, lse, dqkv, dqkv_cls, st);
