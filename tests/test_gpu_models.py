@@ -12,39 +12,13 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TOL_BF16, TOL_BF16_GRAD, TOL_F32, check, compare_grads, gold, relerr, report
+from helpers import AUTOCAST_FACTOR, TOL_BF16, TOL_BF16_GRAD, TOL_F32, cal_entry, check, compare_grads, gold, relerr, report
 from oracle import synth, vt_oracle as O
 from oracle.synth import synth_tensor
 
+from model_common import DEV, PRECS, SMALL, _build, _reset_precision, _train_step  # noqa: F401
+
 pytestmark = pytest.mark.gpu
-DEV = 'cuda:0'
-SMALL = dict(img_size=64, patch_size=16, embed_dims=128, num_heads=2, num_transformer_layers=2)
-PRECS = [('fp32', TOL_F32, TOL_F32), ('bf16', TOL_BF16, TOL_BF16_GRAD)]
-
-
-@pytest.fixture(autouse=True)
-def _reset_precision():
-    import vtx
-    yield
-    vtx.set_precision('auto')
-
-
-def _build(cls, seed, **kw):
-    m = cls(**kw)
-    sd = synth.synth_state_dict(synth.shapes_of(m), seed)
-    m.load_state_dict(sd, strict=True)
-    return m.to(DEV), sd
-
-
-def _train_step(m, x, seed, d):
-    m.train()
-    m.zero_grad()
-    torch.manual_seed(seed)
-    y = m(x.to(DEV))
-    w = (synth_tensor('loss_w', (d,), 0) * 10.0).to(DEV)
-    (y * w).sum().backward()
-    torch.cuda.synchronize()
-    return y, {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
 
 
 @pytest.mark.parametrize('prec,tol,gtol', PRECS)
@@ -58,14 +32,14 @@ def test_timesformer_small_vs_golden(at, prec, tol, gtol):
     x = synth.synth_clip(3, 4, 3, 64, 64, seed=2)
     y, grads = _train_step(m, x, 11, 128)
     assert y.dtype == torch.float32 and y.shape == (3, 128)
-    check(f'tsf_small {at} {prec} train out', y.cpu(), g['out'], tol)
-    compare_grads(f'tsf_small {at} {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
+    check(f'tsf_small {at} {prec} train out', y.cpu(), g['out'], tol, cal=(f'tsf_small {at} train' if prec == 'bf16' else None))
+    compare_grads(f'tsf_small {at} {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'), cal=f'tsf_small {at} train')
     m.eval()
     with torch.no_grad():
-        check(f'tsf_small {at} {prec} eval out', m(x.to(DEV)).cpu(), g['out_eval'], tol)
+        check(f'tsf_small {at} {prec} eval out', m(x.to(DEV)).cpu(), g['out_eval'], tol, cal=(f'tsf_small {at} eval' if prec == 'bf16' else None))
         att = m.get_last_selfattention(x.to(DEV))
     assert tuple(att.shape) == g['attn'].shape
-    check(f'tsf_small {at} {prec} last attention', att.cpu(), g['attn'], tol)
+    check(f'tsf_small {at} {prec} last attention', att.cpu(), g['attn'], tol, cal=(f'tsf_small {at} last attention' if prec == 'bf16' else None))
     assert abs(att.sum(-1).cpu() - 1).max().item() < 1e-3
 
 
@@ -88,11 +62,13 @@ def test_timesformer_other_resolution_vs_oracle(hw, prec, tol, gtol):
     ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     yo = O.timesformer_forward(ps, x, 2, heads=2, layers=2)
     (yo * w).sum().backward()
-    check(f'tsf other resolution {hw} {prec} out', y.detach().cpu(), yo.detach(), tol)
+    check(f'tsf other resolution {hw} {prec} out', y.detach().cpu(), yo.detach(), tol, cal=(f'tsf other resolution {hw}' if prec == 'bf16' else None))
     for k in ('pos_embed', 'time_embed', 'cls_token', 'patch_embed.projection.weight'):
         got, ref = dict(m.named_parameters())[k].grad.cpu(), ps[k].grad
         e = (got.double() - ref.double()).norm().item() / ref.double().norm().item()
-        assert e <= gtol, (k, hw, prec, e)
+        bar = gtol if prec == 'fp32' else max(gtol, AUTOCAST_FACTOR * cal_entry(f'tsf other resolution {hw}')['grad'][k])
+        report(f'{"ok  " if e <= bar else "FAIL"} tsf other resolution {hw} {prec} grad {k}: l2-rel={e:.3e} (tol {bar:g})')
+        assert e <= bar, (k, hw, prec, e)
 
 
 @pytest.mark.parametrize('prec,tol,gtol', PRECS)
@@ -105,115 +81,8 @@ def test_vivit_small_vs_golden(at, prec, tol, gtol):
     m, _ = _build(V.ViViT, 4, num_frames=8, attention_type=at, **SMALL)
     x = synth.synth_clip(3, 8, 3, 64, 64, seed=5)
     y, grads = _train_step(m, x, 13, 128)
-    check(f'vivit_small {at} {prec} train out', y.cpu(), g['out'], tol)
-    compare_grads(f'vivit_small {at} {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
-
-
-@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
-def test_timesformer_b_cfg1_forward(prec, tol):
-    """BASELINE.json configs[0]: TimeSformer-B divided_space_time, 2 frames, batch 2, forward."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision(prec)
-    m, _ = _build(V.TimeSformer, 0, num_frames=2)
-    m.eval()
-    with torch.no_grad():
-        y = m(synth.synth_clip(2, 2, seed=0).to(DEV))
-    check(f'TimeSformer-B cfg1 {prec}', y.cpu(), gold('tsf_b_cfg1.npz')['out'], tol)
-
-
-@pytest.mark.parametrize('prec,tol,gtol', PRECS)
-def test_timesformer_b_t8_train_vs_golden(prec, tol, gtol):
-    """BASELINE.json configs[1] shape (TimeSformer-B, 8x224^2), train mode with DropPath, fwd+bwd."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision(prec)
-    g = gold('tsf_b_t8_autocast.npz')                 # the fp32 run of the reference ('out', gradients) + its autocast run
-    m, _ = _build(V.TimeSformer, 0, num_frames=8)
-    y, grads = _train_step(m, synth.synth_clip(1, 8, seed=1), 7, 768)
-    check(f'TimeSformer-B T=8 train {prec} out', y.cpu(), g['out'], tol)
-    compare_grads(f'TimeSformer-B T=8 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
-    ge = gold('tsf_b_t8_eval.npz')
-    m.eval()
-    with torch.no_grad():
-        x = synth.synth_clip(1, 8, seed=1).to(DEV)
-        check(f'TimeSformer-B T=8 eval {prec} out', m(x).cpu(), ge['out'], tol)
-        att = m.get_last_selfattention(x)
-    assert list(att.shape) == list(ge['attn_shape'])                 # [8, 12, 197, 197]
-    check(f'TimeSformer-B T=8 {prec} attention', att[:2, :, :8, :8].cpu(), ge['attn_head'], tol)
-
-
-@pytest.mark.parametrize('prec,tol,gtol', PRECS)
-def test_timesformer_b_t16_train_vs_golden(prec, tol, gtol):
-    """The north_star's second clip shape: TimeSformer-B on 16x3x224x224, train mode with DropPath,
-    fwd+bwd against the reference's own run (tests/golden/make_golden_r2.py).  Temporal attention
-    here packs two 16-token sequences per 32-row MFMA tile."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision(prec)
-    g = gold('tsf_b_t16_train.npz')
-    m, _ = _build(V.TimeSformer, 0, num_frames=16)
-    y, grads = _train_step(m, synth.synth_clip(1, 16, seed=21), 9, 768)
-    check(f'TimeSformer-B T=16 train {prec} out', y.cpu(), g['out'], tol)
-    compare_grads(f'TimeSformer-B T=16 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
-
-
-def test_timesformer_b_t8_bf16_vs_reference_autocast():
-    """The benchmarked configuration and precision (BASELINE cfg 2, bf16) against the reference's fp32 run, with the
-    reference's OWN bf16-autocast run of the same step as the yardstick: every parameter gradient within 2x of the
-    deviation the reference's AMP shows for that tensor (floor 1e-2), the median within 1.25x, outputs within 1.3x."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision('bf16')
-    g = gold('tsf_b_t8_autocast.npz')
-    m, _ = _build(V.TimeSformer, 0, num_frames=8)
-    y, grads = _train_step(m, synth.synth_clip(1, 8, seed=1), 7, 768)
-    e = check('TimeSformer-B T=8 train bf16 out (r2 golden)', y.cpu(), g['out'], TOL_BF16)
-    ref_dev = relerr(g['out_autocast'], g['out'])
-    report(f'     reference autocast output deviation {ref_dev:.3e}, this path {e:.3e}')
-    assert e <= 1.3 * ref_dev, f'bf16 outputs deviate {e:.3e}, more than 1.3x the reference autocast run ({ref_dev:.3e})'
-    compare_grads('TimeSformer-B T=8 train bf16 vs reference autocast', grads, g, TOL_BF16_GRAD, autocast_cal=True)
-
-
-@pytest.mark.parametrize('prec,tol,gtol', PRECS)
-def test_vivit_b_t16_train_vs_golden(prec, tol, gtol):
-    """BASELINE.json configs[2] at full size, TRAIN mode fwd+bwd: ViViT-B fact_encoder, Conv3d tubelets, 16x224^2,
-    batch 2 (so that the reference's `x[:b, 0]` cls quirk between the two encoders matters), all 231 gradients."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision(prec)
-    g = gold('vivit_b_t16_train.npz')
-    m, _ = _build(V.ViViT, 0, num_frames=16)
-    y, grads = _train_step(m, synth.synth_clip(2, 16, seed=3), 17, 768)
-    check(f'ViViT-B T=16 train {prec} out', y.cpu(), g['out'], tol)
-    compare_grads(f'ViViT-B T=16 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
-
-
-@pytest.mark.parametrize('prec,tol,gtol', PRECS)
-def test_timesformer_l_t96_train_vs_golden(prec, tol, gtol):
-    """BASELINE.json configs[4] geometry: TimeSformer-L (D 1024, 16 heads, hidden 4096) on 96x224^2 clips -- 18 817
-    tokens per clip, temporal attention over 96 frames, 96-frame cls mean -- at depth 2, train mode fwd+bwd."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision(prec)
-    g = gold('tsf_l_t96_d2_train.npz')
-    m, _ = _build(V.TimeSformer, 0, num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=2)
-    y, grads = _train_step(m, synth.synth_clip(1, 96, seed=5), 19, 1024)
-    check(f'TimeSformer-L T=96 depth 2 train {prec} out', y.cpu(), g['out'], tol)
-    compare_grads(f'TimeSformer-L T=96 depth 2 train {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'))
-
-
-@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
-def test_vivit_b_forward(prec, tol):
-    """BASELINE.json configs[2] shape: ViViT-B fact_encoder, Conv3d tubelets, 16 frames."""
-    import vtx
-    import video_transformer as V
-    vtx.set_precision(prec)
-    m, _ = _build(V.ViViT, 0, num_frames=16)
-    m.eval()
-    with torch.no_grad():
-        y = m(synth.synth_clip(2, 16, seed=3).to(DEV))
-    check(f'ViViT-B fact_encoder {prec}', y.cpu(), gold('vivit_b_t16_eval.npz')['out'], tol)
+    check(f'vivit_small {at} {prec} train out', y.cpu(), g['out'], tol, cal=(f'vivit_small {at} train' if prec == 'bf16' else None))
+    compare_grads(f'vivit_small {at} {prec}', grads, g, gtol, exact_elements=(prec == 'fp32'), cal=f'vivit_small {at} train')
 
 
 def test_block_recompute_gives_identical_gradients():
@@ -486,43 +355,27 @@ def test_autocast_selects_bf16_path():
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
-def test_maskfeat_head_vs_golden(prec, tol):
-    """MaskFeat head (blend + decoder + centre-frame masked MSE) against the reference's own
-    MaskFeat.forward run on a stand-in backbone (tests/golden/make_golden.py)."""
+def test_vivit_fact_encoder_width_above_1024(prec, tol):
+    """ViViT fact_encoder with embed_dims 1152: vtx_fact_glue_fwd takes rows up to 1024 wide, wider models run the glue between the
+    two encoders (reference video_transformer.py:515-523) as device-side ATen ops instead of failing."""
     import vtx
     import video_transformer as V
     vtx.set_precision(prec)
-    g = gold('maskfeat_head.npz')
-    mask = torch.from_numpy(g['mask'])
-    markers = json.loads(str(g['markers']))
-
-    class StandIn(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.register_buffer('w', synth_tensor('standin.w', (768, 96), 0))
-
-        def forward(self, t):
-            t = t.float()
-            b = t.shape[0]
-            v = t.reshape(b, 8, 14, 4, 14, 4, 96).mean(dim=(3, 5)).reshape(b, 1568, 96) @ self.w.t()
-            return torch.cat([v.mean(1, keepdim=True), v], dim=1)
-
-    m = V.MaskFeat(pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]], feature_dim=2 * 2 * 2 * 3 * 9, backbone=StandIn())
-    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if 'mvit' not in k}, seed=6)
-    m.load_state_dict(sd, strict=False)
-    m.to(DEV).train()
-    x = synth.synth_clip(2, 16, seed=8).to(DEV)
-    target = torch.rand(2, 16, 14, 14, 108, generator=torch.Generator().manual_seed(99), dtype=torch.float64)
-    pred, loss = m(x, target.to(DEV), mask.to(DEV), markers)
-    loss.backward()
-    assert pred.shape == (2, 16, 14, 14, 108) and loss.dtype == torch.float64
-    rel = abs(loss.item() - float(g['loss'])) / float(g['loss'])
-    report(f'maskfeat {prec}: loss {loss.item():.9f} vs reference {float(g["loss"]):.9f} (rel {rel:.2e})')
-    assert rel < tol
-    check(f'maskfeat {prec} pred', pred[:, :, :2, :2].cpu(), g['pred_head'], tol)
-    check(f'maskfeat {prec} d decoder bias', m.decoder_pred.bias.grad.cpu(), g['d_decoder_b'], 2 * tol)
-    check(f'maskfeat {prec} d decoder weight', m.decoder_pred.weight.grad[:8].cpu(), g['d_decoder_w_head'], 2 * tol)
-    check(f'maskfeat {prec} d mask_token', m.mask_token.grad.cpu(), g['d_mask_token'], 4 * tol)
+    m, sd = _build(V.ViViT, 8, num_frames=4, img_size=32, patch_size=16, embed_dims=1152, num_heads=18, num_transformer_layers=1)
+    x = synth.synth_clip(2, 4, 3, 32, 32, seed=9)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = O.vivit_forward(ps, x, 4, heads=18, layers=1)
+    (yo * synth_tensor('loss_w', (1152,), 0)).sum().backward()
+    m.eval()
+    m.zero_grad()
+    y = m(x.to(DEV))
+    (y * synth_tensor('loss_w', (1152,), 0).to(DEV)).sum().backward()
+    check(f'vivit fact_encoder D=1152 {prec} out', y.detach().cpu(), yo.detach(), tol)
+    gtol = TOL_F32 if prec == 'fp32' else TOL_BF16_GRAD
+    for k in ('time_embed', 'cls_token', 'pos_embed'):
+        got, ref = dict(m.named_parameters())[k].grad.cpu(), ps[k].grad
+        e = (got.double() - ref.double()).norm().item() / ref.double().norm().item()
+        assert e <= gtol, (k, prec, e)
 
 
 def test_hip_vs_oracle_fresh_seed():

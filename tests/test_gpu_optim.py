@@ -71,7 +71,7 @@ def test_unused_parameters_take_no_update():
     o_ref = torch.optim.AdamW(p_ref, lr=0.01, weight_decay=0.1)
     o_gpu = optim.FusedAdamW(p_gpu, lr=0.01, weight_decay=0.1)
     unused = {1, 4}
-    for step in range(3):
+    for step in range(5):
         grads = _params(20 + step)
         for i, (pr, pg, g) in enumerate(zip(p_ref, p_gpu, grads)):
             pr.grad = None if i in unused else g.clone().double()
@@ -81,10 +81,14 @@ def test_unused_parameters_take_no_update():
         o_gpu.step()
         if step == 1:
             unused = {4}                                # parameter 1 joins the graph later: its first update is step 1 of ITS history
-            # (torch keeps a per-parameter step count; the fused class keeps one for all -- compare the untouched one only)
     check('unused parameter stays put', p_gpu[4].detach().cpu(), init[4], 0.0 + 1e-12)
-    for i in (0, 2, 3, 5, 6, 7):
+    # parameter 1 was skipped twice and updated three times: torch's per-parameter step count gives its bias correction for update
+    # 1, 2, 3 -- the fused class keeps per-parameter counts too and launches it on its own table
+    for i in (0, 1, 2, 3, 5, 6, 7):
         check(f'used parameter {i}', p_gpu[i].detach().cpu(), p_ref[i].detach(), 2e-6)
+    steps = {i: float(st['step']) for i, st in o_gpu.state_dict()['state'].items()}
+    assert steps[0] == 5.0 and steps[1] == 3.0 and 4 not in steps, steps
+    assert {i: float(st['step']) for i, st in o_ref.state_dict()['state'].items()} == steps
     sd = o_gpu.state_dict()
     assert all('step' not in st for st in o_gpu.state.values()), "state_dict() must not leave a 'step' key in the live state"
     assert all('step' in st for st in sd['state'].values())

@@ -1540,7 +1540,9 @@ __global__ __launch_bounds__(HW ? 1024 : MA_THREADS) void attn_fwd_small_kernel(
   // HW: the head groups of a row tile are CONSECUTIVE workgroups (blockIdx.x = head group): they run at the same time and read
   // neighbouring 128-byte segments of the same rows -- with the tile index fastest the groups of one tile were a whole grid row
   // apart (temporal backward, 4 heads per workgroup: 356 -> 332 us)
-  const int tile = HW ? blockIdx.y : blockIdx.x * 4 + wave, h = HW ? wave + blockIdx.x * (blockDim.x >> 6) : blockIdx.y, D = p.H * 64;
+  // (head group, tile) folded into blockIdx.x, head group fastest -- grid.y stops at 65535 tiles, grid.x at 2^31
+  const int hw_w = blockDim.x >> 6, hw_ng = HW ? (p.H + hw_w - 1) / hw_w : 1;
+  const int tile = HW ? (int)(blockIdx.x / hw_ng) : blockIdx.x * 4 + wave, h = HW ? wave + (int)(blockIdx.x % hw_ng) * hw_w : blockIdx.y, D = p.H * 64;
   if (tile >= ntiles || h >= p.H) return;
   bf16raw* Vs = reinterpret_cast<bf16raw*>(sm_raw + wave * SM_WAVE_LDS_FWD);
   const int L = p.L, G = 32 / L, used = G * L;
@@ -1606,7 +1608,9 @@ __global__ __launch_bounds__(HW ? 1024 : MA_THREADS, HW ? 1 : 4) void attn_bwd_s
   // HW: the head groups of a row tile are CONSECUTIVE workgroups (blockIdx.x = head group): they run at the same time and read
   // neighbouring 128-byte segments of the same rows -- with the tile index fastest the groups of one tile were a whole grid row
   // apart (temporal backward, 4 heads per workgroup: 356 -> 332 us)
-  const int tile = HW ? blockIdx.y : blockIdx.x * 4 + wave, h = HW ? wave + blockIdx.x * (blockDim.x >> 6) : blockIdx.y, D = p.H * 64;
+  // (head group, tile) folded into blockIdx.x, head group fastest -- grid.y stops at 65535 tiles, grid.x at 2^31
+  const int hw_w = blockDim.x >> 6, hw_ng = HW ? (p.H + hw_w - 1) / hw_w : 1;
+  const int tile = HW ? (int)(blockIdx.x / hw_ng) : blockIdx.x * 4 + wave, h = HW ? wave + (int)(blockIdx.x % hw_ng) * hw_w : blockIdx.y, D = p.H * 64;
   if (tile >= ntiles || h >= p.H) return;
   // two wave-private tiles: A holds K for phase 1 (and stages dQ), then Q for phase 2 (and stages dK); B holds dO
   // (and stages dV) -- 8.25 KB per wave instead of 12.25 KB: LDS is what bounds the waves per CU of this kernel
@@ -1743,7 +1747,7 @@ int attn_fwd_small_launch(const AttnP& p, const void* qkv, void* out, float* lse
   const int ntiles = (p.S + G - 1) / G;
   if (options().attn_hw_fwd > 0) {
     const int w = hw_waves(options().attn_hw_fwd, p.H);
-    hipLaunchKernelGGL(attn_fwd_small_kernel<true>, dim3((p.H + w - 1) / w, ntiles), dim3(64 * w), w * SM_WAVE_LDS_FWD, st, p, ntiles,
+    hipLaunchKernelGGL(attn_fwd_small_kernel<true>, dim3(((p.H + w - 1) / w) * ntiles), dim3(64 * w), w * SM_WAVE_LDS_FWD, st, p, ntiles,
                        (const bf16raw*)qkv, (bf16raw*)out, lse);
   } else {
     hipLaunchKernelGGL(attn_fwd_small_kernel<false>, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_FWD, st, p, ntiles,
@@ -1762,7 +1766,7 @@ int attn_bwd_small_launch(const AttnP& p, const void* qkv, const void* o, const 
     if (first_launch_on_device(attr_set)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL(attn_bwd_small_kernel<true>, dim3((p.H + w - 1) / w, ntiles), dim3(64 * w), lds, st, p, ntiles,
+    hipLaunchKernelGGL(attn_bwd_small_kernel<true>, dim3(((p.H + w - 1) / w) * ntiles), dim3(64 * w), lds, st, p, ntiles,
                        (const bf16raw*)qkv, (const bf16raw*)o, (const bf16raw*)dout, lse, (bf16raw*)dqkv);
   } else {
     hipLaunchKernelGGL(attn_bwd_small_kernel<false>, dim3((ntiles + 3) / 4, p.H), dim3(MA_THREADS), 4 * SM_WAVE_LDS_BWD, st, p, ntiles,

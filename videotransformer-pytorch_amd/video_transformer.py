@@ -274,7 +274,16 @@ class ViViT(_VideoTransformerBase):
     def _fact_temporal_tokens(self, x, b):
         """Glue between the spatial and temporal encoders (reference :515-523), kept
         literal: the cls rows are the first b rows of the flattened (b t) axis."""
-        return F_.FactGlueFn.apply(x, _embed(self.time_embed, x.device), b)
+        D = x.shape[2]
+        if D % 8 == 0 and D <= 1024 and x.dtype == vtx.compute_dtype():
+            return F_.FactGlueFn.apply(x, _embed(self.time_embed, x.device), b)
+        # widths vtx_fact_glue_fwd does not take (16-byte vectors of a row, one row per workgroup pass): the same expressions
+        # as device-side ATen ops between the two encoders (round 3's form; not on any BASELINE configuration)
+        x32 = F_.CastFn.apply(x, torch.float32)
+        cls_b = x32[:b, 0:1]
+        frames = x32[:, 1:].reshape(b, -1, x32.shape[1] - 1, x32.shape[2]).mean(2)
+        h = torch.cat([cls_b, frames], dim=1) + _embed(self.time_embed, x.device)
+        return F_.CastFn.apply(h.contiguous(), vtx.compute_dtype())
 
     def forward(self, x):
         x, cls_tokens, b = self.prepare_tokens(x)

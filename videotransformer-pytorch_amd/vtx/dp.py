@@ -70,10 +70,12 @@ class GradBuckets:
             self._close(cur)
         self._hooks = []
         self._fired = set()                     # id() of the parameters whose gradient has arrived since zero()
+        self._unfired_cache = None
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self._launched = []
+        self._next = 0                          # the next bucket to go out (see _launch_ready)
 
     def _close(self, plist):
         # every gradient view starts on a 16-byte boundary (the kernels that write gradients in place take 16-byte vectors):
@@ -105,8 +107,19 @@ class GradBuckets:
             self._fired.add(id(p))
             b['pending'] -= 1
             if b['pending'] == 0:
-                self._launch(b)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Collectives are issued strictly in bucket order: bucket k goes out when its last gradient has arrived AND buckets
+        0 .. k-1 have gone out.  Every rank must issue the same sequence of all-reduces; a rank on which some parameter stays
+        unused this step (a data-dependent branch) completes its buckets in another order than its peers, and issuing them in
+        completion order would pair different buckets across ranks (found by tests/test_dp_gloo.py::
+        test_unfired_parameters_are_agreed_across_ranks; torch DDP orders its buckets the same way).  With every parameter used,
+        bucket order IS completion order (reverse registration order = the order backward produces gradients)."""
+        while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b):
         if self.world == 1 and not self.force_comm:
@@ -140,9 +153,16 @@ class GradBuckets:
             b['comm'] = None
         self._launched = []
         self._fired = set()
+        self._unfired_cache = None
+        self._next = 0
 
     def finish(self):
         """Wait for every bucket's all-reduce; afterwards param.grad holds the mean gradient."""
+        # buckets that have not gone out yet (a parameter without a gradient this step holds its bucket -- and every later
+        # one -- back): now, in bucket order, so that every rank issues the same sequence
+        while self._next < len(self.buckets):
+            self._launch(self.buckets[self._next])
+            self._next += 1
         for b in self._launched:
             b['handle'].wait()
             if b.get('host') is not None:
@@ -151,17 +171,27 @@ class GradBuckets:
                 b['flat'].copy_(b['comm'])
             if not b['avg_in_op']:
                 b['flat'].div_(self.world)
-        # buckets whose hooks never all fired (unused parameters): reduce them now
-        if self.world > 1:
-            for b in self.buckets:
-                if b['handle'] is None:
-                    all_reduce_sum(b['flat'], self.group)
-                    b['flat'].div_(self.world)
         self._launched = []
 
     def unfired(self):
-        """The parameters whose gradient has NOT arrived since zero(): unused in this step's graph (their .grad view is all zero)."""
-        return [p for b in self.buckets for p in b['params'] if id(p) not in self._fired]
+        """The parameters whose gradient has NOT arrived since zero() ON ANY RANK: unused in this step's graph everywhere (their
+        mean gradient is zero).  COLLECTIVE when the group has more than one rank -- every rank calls it once per step, after
+        finish(): the per-parameter "fired" bitmap is all-reduced with MAX, the way DDP's find_unused_parameters=True shares its
+        used-parameter bitmap, so that a parameter used on one rank only (a data-dependent branch) is updated with the averaged
+        gradient on EVERY rank -- skipping it on the ranks that did not use it would let the replicas drift apart silently
+        (ADVICE r4).  The result is cached until the next zero()."""
+        if self._unfired_cache is not None:
+            return self._unfired_cache
+        params = [p for b in self.buckets for p in b['params']]
+        fired = [1 if id(p) in self._fired else 0 for p in params]
+        if self.world > 1:
+            flags = torch.tensor(fired, dtype=torch.int32)
+            if dist.get_backend(self.group) == 'nccl':
+                flags = flags.to(params[0].device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            fired = flags.cpu().tolist()
+        self._unfired_cache = [p for p, f in zip(params, fired) if not f]
+        return self._unfired_cache
 
     def remove(self):
         for h in self._hooks:

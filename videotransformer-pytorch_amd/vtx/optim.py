@@ -16,6 +16,10 @@ import torch
 from . import _lib, ops
 
 
+class _Table:
+    """One launch's device table: (param, grad, state) pointers, chunk starts, norm scratch."""
+
+
 class _FusedBase(torch.optim.Optimizer):
     def __init__(self, params, defaults, clip_grad=None):
         if hasattr(params, 'buckets'):                  # a vtx.dp.GradBuckets: its parameters, in bucket order
@@ -24,7 +28,8 @@ class _FusedBase(torch.optim.Optimizer):
         self.clip_grad = clip_grad
         self.last_grad_norm = None                      # device scalar: ||(per-parameter norms)||_2 of the last step
         self._key = None
-        self._n_steps = 0
+        self._tables = []
+        self._steps = {}                                # id(parameter) -> number of updates it has taken (torch: state[p]['step'])
         self._skipped = frozenset()                     # id() of parameters that take no update (see set_skipped)
 
     def set_skipped(self, params):
@@ -54,10 +59,17 @@ class _FusedBase(torch.optim.Optimizer):
     def _state_tensors(self, p):
         raise NotImplementedError
 
+    def _partition(self, ent):
+        """Entries that one launch can update together.  SGD: all of them.  AdamW: the bias correction depends on a parameter's
+        OWN update count (torch keeps state[p]['step'] per parameter), so parameters that were skipped for some steps
+        (set_skipped) form their own launch -- one table in the usual case where every parameter has been updated equally often."""
+        return [ent]
+
     def _build(self, ent):
         lib = _lib.load()
         dev = ent[0][0].device
         ops.need_cuda(*[p for p, _ in ent])
+        t = _Table()
         tab = (_lib.MtTensor * len(ent))()
         starts = [0]
         for i, (p, gi) in enumerate(ent):
@@ -66,40 +78,49 @@ class _FusedBase(torch.optim.Optimizer):
             tab[i].s1, tab[i].s2 = s1.data_ptr(), (s2.data_ptr() if s2 is not None else None)
             tab[i].n = p.numel()
             starts.append(starts[-1] + lib.vtx_mt_chunks(p.numel()))
-        self._tab_host = tab
-        self._groups_of = [gi for _, gi in ent]
-        self._n_chunks = starts[-1]
-        self._chunk_start = torch.tensor(starts, dtype=torch.int32).to(dev)
-        self._tab_dev = torch.empty(C.sizeof(tab), dtype=torch.uint8, device=dev)
-        self._partial = torch.empty(self._n_chunks, dtype=torch.float32, device=dev)
-        self._norms = torch.zeros(len(ent) + 1, dtype=torch.float32, device=dev)
-        self._hyper = None
+        t.params = [p for p, _ in ent]
+        t.tab_host = tab
+        t.groups_of = [gi for _, gi in ent]
+        t.n_chunks = starts[-1]
+        t.chunk_start = torch.tensor(starts, dtype=torch.int32).to(dev)
+        t.tab_dev = torch.empty(C.sizeof(tab), dtype=torch.uint8, device=dev)
+        t.partial = torch.empty(t.n_chunks, dtype=torch.float32, device=dev)
+        t.norms = torch.zeros(len(ent) + 1, dtype=torch.float32, device=dev)
+        t.hyper = None
+        return t
 
     def _sync_tables(self):
+        """The device tables of this step's launches: a list of _Table (empty when no parameter has a gradient)."""
         ent = self._entries()
         if not ent:
-            return False
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p, _ in ent)
+            return []
+        parts = self._partition(ent)
+        key = tuple(tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p, _ in part) for part in parts)
         if key != self._key:
-            self._build(ent)
+            self._tables = [self._build(part) for part in parts]
             self._key = key
         hyper = tuple((float(g['lr']), float(g['weight_decay'])) for g in self.param_groups)
-        if hyper != self._hyper:                        # schedulers rewrite lr / weight_decay between steps
-            for i, gi in enumerate(self._groups_of):
-                self._tab_host[i].lr, self._tab_host[i].wd = hyper[gi]
-            raw = bytes(self._tab_host)
-            self._tab_dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8), non_blocking=False)
-            self._hyper = hyper
-        return True
+        for t in self._tables:
+            if hyper != t.hyper:                        # schedulers rewrite lr / weight_decay between steps
+                for i, gi in enumerate(t.groups_of):
+                    t.tab_host[i].lr, t.tab_host[i].wd = hyper[gi]
+                raw = bytes(t.tab_host)
+                t.tab_dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8), non_blocking=False)
+                t.hyper = hyper
+        return self._tables
 
     def grad_norm(self):
         """||(||g_0||, ||g_1||, ...)||_2 over the parameters that have gradients, as a device scalar -- what
         the reference's clip_gradients returns (model_trainer.py:169)."""
-        if not self._sync_tables():
+        tables = self._sync_tables()
+        if not tables:
             return None
-        _lib.call('vtx_mt_grad_norms', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
-                  self._n_chunks, self._partial.data_ptr(), self._norms.data_ptr(), ops.stream())
-        return self._norms[-1]
+        for t in tables:
+            _lib.call('vtx_mt_grad_norms', t.tab_dev.data_ptr(), t.chunk_start.data_ptr(), len(t.groups_of),
+                      t.n_chunks, t.partial.data_ptr(), t.norms.data_ptr(), ops.stream())
+        if len(tables) == 1:
+            return tables[0].norms[-1]
+        return torch.stack([t.norms[-1] for t in tables]).norm()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -107,13 +128,16 @@ class _FusedBase(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self._sync_tables():
+        tables = self._sync_tables()
+        if not tables:
             return loss
         clip = float(self.clip_grad) if self.clip_grad else 0.0
         if clip > 0.0:
             self.last_grad_norm = self.grad_norm()
-        self._n_steps += 1
-        self._launch(clip)
+        for t in tables:
+            for p in t.params:
+                self._steps[id(p)] = self._steps.get(id(p), 0) + 1
+            self._launch(t, clip, self._steps[id(t.params[0])])
         self._bump_versions()
         # the staged bf16 W / W^T copies of the updated weights: one launch now instead of one per weight in the next forward
         from . import functions
@@ -130,7 +154,7 @@ class _FusedBase(torch.optim.Optimizer):
                 if p.grad is not None:
                     p.view(-1)[:0].zero_()
 
-    def _launch(self, clip):
+    def _launch(self, table, clip, step):
         raise NotImplementedError
 
     # ---- checkpoint surface ----------------------------------------------------------------------
@@ -147,18 +171,19 @@ class _FusedBase(torch.optim.Optimizer):
         # torch packs the LIVE per-parameter dicts by reference: add the 'step' entry to shallow copies, or every save would leave
         # a stale key in the optimizer's own state.  One tensor PER parameter: torch.optim.AdamW increments each parameter's
         # 'step' in place after loading such a dict -- a shared tensor would count every parameter's update.
-        sd['state'] = {k: {**v, 'step': torch.tensor(float(self._n_steps))} for k, v in sd['state'].items()}
+        index_of = {}
+        for group in self.param_groups:                 # torch numbers the parameters in param_groups order
+            for p in group['params']:
+                index_of[len(index_of)] = p
+        sd['state'] = {k: {**v, 'step': torch.tensor(float(self._steps.get(id(index_of[k]), 0)))} for k, v in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = set()
-        for st in self.state.values():
+        self._steps = {}
+        for p, st in self.state.items():
             if 'step' in st:
-                steps.add(int(float(st.pop('step'))))
-        if len(steps) > 1:
-            raise NotImplementedError(f'vtx.optim: one update count for all parameters expected, the state dict holds {sorted(steps)}')
-        self._n_steps = steps.pop() if steps else 0
+                self._steps[id(p)] = int(float(st.pop('step')))
         self._key = None                                # the loaded state tensors are new tensors
 
 
@@ -180,14 +205,14 @@ class FusedSGD(_FusedBase):
             st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st['momentum_buffer'], None
 
-    def _launch(self, clip):
+    def _launch(self, t, clip, step):
         g0 = self.param_groups[0]
         if any(g['momentum'] != g0['momentum'] or g['nesterov'] != g0['nesterov'] for g in self.param_groups):
             raise NotImplementedError('vtx.optim.FusedSGD: momentum / nesterov must be the same in every group')
         if any(g.get('dampening', 0) or g.get('maximize', False) for g in self.param_groups):
             raise NotImplementedError('vtx.optim.FusedSGD: dampening / maximize are not implemented')
-        _lib.call('vtx_mt_sgd_step', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
-                  self._n_chunks, self._norms.data_ptr(), clip, float(g0['momentum']), int(bool(g0['nesterov'])),
+        _lib.call('vtx_mt_sgd_step', t.tab_dev.data_ptr(), t.chunk_start.data_ptr(), len(t.groups_of),
+                  t.n_chunks, t.norms.data_ptr(), clip, float(g0['momentum']), int(bool(g0['nesterov'])),
                   0, ops.stream())
 
 
@@ -206,12 +231,18 @@ class FusedAdamW(_FusedBase):
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st['exp_avg'], st['exp_avg_sq']
 
-    def _launch(self, clip):
+    def _partition(self, ent):
+        by_step = {}
+        for e in ent:
+            by_step.setdefault(self._steps.get(id(e[0]), 0), []).append(e)
+        return [by_step[k] for k in sorted(by_step, reverse=True)]
+
+    def _launch(self, t, clip, step):
         g0 = self.param_groups[0]
         if any(g['betas'] != g0['betas'] or g['eps'] != g0['eps'] for g in self.param_groups):
             raise NotImplementedError('vtx.optim.FusedAdamW: betas / eps must be the same in every group')
         if any(g.get('amsgrad', False) or g.get('maximize', False) or not g.get('decoupled_weight_decay', True) for g in self.param_groups):
             raise NotImplementedError('vtx.optim.FusedAdamW: amsgrad / maximize / coupled weight decay are not implemented')
-        _lib.call('vtx_mt_adamw_step', self._tab_dev.data_ptr(), self._chunk_start.data_ptr(), len(self._groups_of),
-                  self._n_chunks, self._norms.data_ptr(), clip, float(g0['betas'][0]), float(g0['betas'][1]),
-                  float(g0['eps']), self._n_steps, ops.stream())
+        _lib.call('vtx_mt_adamw_step', t.tab_dev.data_ptr(), t.chunk_start.data_ptr(), len(t.groups_of),
+                  t.n_chunks, t.norms.data_ptr(), clip, float(g0['betas'][0]), float(g0['betas'][1]),
+                  float(g0['eps']), step, ops.stream())
