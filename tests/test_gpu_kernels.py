@@ -565,6 +565,46 @@ def test_gemm_tn(dtype, M, N1, N2, vtx_opts):
     check(f'gemm_tn accumulate {dtype}', C0.cpu(), ref + 1, 2e-3)
 
 
+@pytest.mark.parametrize('M,N1,N2', [(12552, 768, 768), (12544, 2304, 768), (150528 // 8 + 37, 768, 3072), (4096, 256, 256),
+                                      (33000, 256, 512), (8 * 1569, 3072, 768)])
+@pytest.mark.parametrize('cs', [False, True])
+def test_gemm_tn_one_wave_per_simd_equals_ping_pong(M, N1, N2, cs, vtx_opts):
+    """gemm_tn=w4 (round 5: four waves per workgroup, one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs, fragment reads
+    and LDS-DMA requests in the MFMA gaps) against gemm_tn=pp256: the same tile / slab partition, the same products summed in
+    the same order per accumulator -- weight gradients and fused bias-gradient column sums BIT-identical; and against float64.
+    Shapes: K-tile counts per slab odd / even / 2 (the pairs-then-odd-tile loop, the ragged last tile), token-row maps with the
+    group boundary inside a K tile, 9 ... 36 output tiles."""
+    from vtx import ops
+    dtype = torch.bfloat16
+    A, Bm = rnd(M, N1, seed=1), rnd(M, N2, seed=2)
+    Ad, Bd = dev(A, dtype), dev(Bm, dtype)
+    res = {}
+    for v in ('pp256', 'w4', 'w4'):
+        vtx_opts('gemm_tn', v)
+        r = ops.gemm_tn(Ad, Bd, M, N1, N2, want_colsum=cs)
+        torch.cuda.synchronize()
+        res.setdefault(v, []).append(r if cs else (r, None))
+    C_pp, cs_pp = res['pp256'][0]
+    for C_w, cs_w in res['w4']:
+        assert torch.equal(C_w, C_pp), f'w4 != pp256: max diff {(C_w - C_pp).abs().max().item():.3e}'
+        if cs:
+            assert torch.equal(cs_w, cs_pp)
+    if M <= 20000:
+        check(f'gemm_tn w4 {M}x{N1}x{N2} vs f64', C_pp.cpu(), q(A, dtype).t() @ q(Bm, dtype), 2e-3)
+    if N1 == 256:                                     # token-row maps (cls rows skipped) on both operands
+        Bp, Np = 4, M // 4 - 1
+        Xp, Yp = rnd(Bp, 1 + Np, N1, seed=11), rnd(Bp, 1 + Np, N2, seed=12)
+        tm = ops.tokmap(Np)
+        out = []
+        for v in ('pp256', 'w4'):
+            vtx_opts('gemm_tn', v)
+            out.append(ops.gemm_tn(dev(Xp, dtype), dev(Yp, dtype), Bp * Np, N1, N2, amap=tm, bmap=tm, want_colsum=True))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        if M <= 20000:
+            check(f'gemm_tn w4 rowmaps {M}x{N1}x{N2} vs f64', out[1][0].cpu(),
+                  q(Xp, dtype)[:, 1:].reshape(Bp * Np, N1).t() @ q(Yp, dtype)[:, 1:].reshape(Bp * Np, N2), 2e-3)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_gemm_tn_rowmap_and_colsum(dtype):
     from vtx import ops

@@ -28,7 +28,7 @@ int check_launch(const char* what) {
 
 // ---- options -------------------------------------------------------------------------
 static const char* const kNtNames[] = {"auto", "pp256", "dma2", "ring128x3", "ring128x4k32", "ring256x3", "ring256x3k32", "ring256x4k32"};
-static const char* const kTnNames[] = {"auto", "pp256", "ring", "dma2"};
+static const char* const kTnNames[] = {"auto", "pp256", "ring", "dma2", "w4"};
 
 static int parse_enum(const char* v, const char* const* names, int n) {
   for (int i = 0; i < n; ++i)
@@ -39,7 +39,7 @@ static int parse_enum(const char* v, const char* const* names, int n) {
 static int set_option(Options& o, const char* name, const char* value) {
   if (!name || !value) return VTX_EINVAL;
   if (strcmp(name, "gemm_nt") == 0) { const int e = parse_enum(value, kNtNames, 8); if (e < 0) return VTX_EINVAL; o.gemm_nt = e; return VTX_OK; }
-  if (strcmp(name, "gemm_tn") == 0) { const int e = parse_enum(value, kTnNames, 4); if (e < 0) return VTX_EINVAL; o.gemm_tn = e; return VTX_OK; }
+  if (strcmp(name, "gemm_tn") == 0) { const int e = parse_enum(value, kTnNames, 5); if (e < 0) return VTX_EINVAL; o.gemm_tn = e; return VTX_OK; }
   if (strcmp(name, "gemm_nodma") == 0) { o.gemm_nodma = atoi(value) != 0; return VTX_OK; }
   if (strcmp(name, "tn_safe") == 0) { o.tn_safe = atoi(value) != 0; return VTX_OK; }
   if (strcmp(name, "attn_valu") == 0) { o.attn_valu = atoi(value) != 0; return VTX_OK; }

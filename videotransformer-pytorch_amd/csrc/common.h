@@ -163,7 +163,7 @@ __device__ inline void gelu_erf_both(float x, float& val, float& grad) {
 // Process-wide, set through vtx_set_option() (initial values come from the VTX_* environment
 // variables, read ONCE when the library is first used -- never on the launch path).
 enum { NT_AUTO = 0, NT_PP256, NT_DMA2, NT_RING128X3, NT_RING128X4K32, NT_RING256X3, NT_RING256X3K32, NT_RING256X4K32 };
-enum { TN_AUTO = 0, TN_PP256, TN_RING, TN_DMA2 };
+enum { TN_AUTO = 0, TN_PP256, TN_RING, TN_DMA2, TN_W4 };
 struct Options {
   int gemm_nt = NT_AUTO;     // VTX_GEMM_NT: kernel family override of vtx_gemm_nt (bf16)
   int gemm_tn = TN_AUTO;     // VTX_GEMM_TN: ... of vtx_gemm_tn (bf16)

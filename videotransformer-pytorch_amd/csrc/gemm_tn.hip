@@ -923,6 +923,353 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
 #undef TP_EPI
 }
 
+// ---- bf16, 256x256 output tile, ONE wave per SIMD with 128x128 wave tiles (round 5) --------------
+// The ping-pong kernel above needs 1.5 transpose reads per MFMA (a 128x64 wave tile takes 4 A + 2 B fragments per 8
+// MFMAs, two `ds_read_b64_tr_b16` each) and its two load sections of 16 reads (~380 cycles) outlast the partner group's
+// 8-MFMA section (256): ~3500 cycles per 64-row K tile against the 2048 its 64 MFMAs per SIMD take.  Here
+// a workgroup is 4 waves, one per SIMD, each owning a 128x128 block of the same 256x256 tile: 4 A + 4 B fragments per
+// 16 MFMAs = 1.0 read per MFMA, all 256 accumulator registers of the wave in the AGPR half of the 512-register file.
+// There is no partner wave to hide behind, so the wave pipelines against itself: a K tile is four phases of 16 MFMAs
+//     P1  A0 x B0     P2  A0 x B1     P3  A1 x B1     P4  A1 x B0          (regions as in the ping-pong kernel)
+// and the 16 transpose reads of the fragment set the NEXT phase needs (B1(kt) | A1(kt) | A0(kt+1) | B0(kt+1)) sit one
+// fragment (two reads) per gap behind the first eight MFMAs of the current phase, the four LDS-DMA pieces that refill
+// the region the PREVIOUS phase has just released (B0(kt+2) | B1(kt+2) | A1(kt+2) | A0(kt+3): per tile the same A0 B0 B1
+// A1 order as above) behind the next four.  Every phase ends with lgkmcnt(0) (the set is complete, the region's last
+// reader is done), a counted vmcnt (this wave's pieces of the region the next phase reads have landed: six regions = 24
+// requests were issued after it), and ONE barrier that publishes both facts.  Same LDS image, piece shapes, swizzle,
+// row-state machine and slab / column-sum outputs as the ping-pong kernel (a wave owns four pieces per region instead
+// of two); same products summed in the same order per accumulator: bit-identical slabs.
+constexpr int TW_THREADS = 256;
+constexpr int TW_LDS_BYTES = TP_RING_BYTES + 4 * 16 * TP_STG_LD * 4;
+
+template <bool WANT_CS>
+__global__ __launch_bounds__(TW_THREADS, 1) void gemm_tn_bf16_w4_kernel(
+    int M, int m_per_split, const bf16raw* __restrict__ A, long lda, vtx_rowmap amap,
+    const bf16raw* __restrict__ B, long ldb, vtx_rowmap bmap, int tiles2, int tiles12, TnOut out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16raw* lds = reinterpret_cast<bf16raw*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid / tiles12;
+  const int tile = bid - split * tiles12;
+  const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+  const int r0 = t1 * 256, c0 = t2 * 256;
+  const int m_begin = split * m_per_split;
+  const int m_end = (split == (int)(gridDim.x / tiles12) - 1) ? M : m_begin + m_per_split;   // last split: + remainder
+  const int span = m_end - m_begin;
+  const int nk = (span + TP_BK - 1) / TP_BK;      // >= 2 (host guarantees m_per_split >= 128)
+  const int last_valid = span - (nk - 1) * TP_BK; // rows of the last tile that are inside the span
+
+  // DMA pieces: a region is 16 pieces of 8 token rows x 128 B (piece p: sub-block p / 8, rows 8 * (p % 8) + lane / 8);
+  // this wave owns pieces 4 * wave .. 4 * wave + 3 -- one sub-block, rows prow0 + 8 j, the same swizzle bit for all four.
+  const int pc0 = wave * 4, sub = pc0 >> 3;
+  const int prow0 = (pc0 & 7) * 8 + (lane >> 3);
+  const int rc = sub * 64 + ((lane & 7) ^ (((prow0 >> 1) & 1) << 2)) * 8;   // region column 0..127
+  const int acol_l = (rc >> 6) * 128 + (rc & 63);
+  const unsigned voff_a = 2u * (unsigned)(prow0 * (int)lda + acol_l), voff_b = 2u * (unsigned)(prow0 * (int)ldb + rc);
+  int trm[4], crs[4], vld[4];
+  const char* sp[4];
+  const long step64_a = 2L * TP_BK * lda, step64_b = 2L * TP_BK * ldb;
+  const long skipb_a = 2L * amap.skip * lda, skipb_b = 2L * bmap.skip * ldb;
+  constexpr int TP_FAR = 1 << 28;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool isA = k == 0 || k == 3;
+    const vtx_rowmap& mp = isA ? amap : bmap;
+    const int g = mp.grp;
+    const int q = g > 0 ? m_begin / g : 0;
+    trm[k] = g > 0 ? m_begin - q * g : 0;
+    crs[k] = g > 0 ? g - trm[k] : TP_FAR;
+    vld[k] = M - m_begin;
+    const long phys0 = (long)mp.base + m_begin + (long)q * mp.skip;
+    sp[k] = reinterpret_cast<const char*>(isA ? A + phys0 * lda + r0 + (k == 3 ? 64 : 0) : B + phys0 * ldb + c0 + (k == 2 ? 128 : 0));
+  }
+  auto issue_piece = [&](int kind, int kt, int j) {   // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1; piece j (0..3) of this wave
+    bf16raw* dst = lds + (kt & 1) * TP_BUF + kind * TP_REGION + wave * 2048;
+    const bool isA = kind == 0 || kind == 3;
+    const char* lo = sp[kind];
+    const char* hi = lo + (isA ? skipb_a : skipb_b);
+    const unsigned vo = isA ? voff_a : voff_b, vc = 2u * (unsigned)(isA ? acol_l : rc);
+    const unsigned step8 = 16u * (unsigned)(isA ? lda : ldb);
+    const int row = prow0 + 8 * j;
+    if (crs[kind] >= TP_BK && vld[kind] >= TP_BK) {   // regular K tile: scalar base + the lane's constant offset (see the ping-pong kernel)
+      const unsigned m0v = (unsigned)(unsigned long)(tn_lds_char*)(dst + j * 512);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :: "v"(vo + j * step8), "s"(lo), "s"(m0v) : "memory", "m0");
+      return;
+    }
+    const char* base = row >= crs[kind] ? hi : lo;
+    const unsigned o = row < vld[kind] ? vo + j * step8 : vc;
+    tn_dma16(reinterpret_cast<const bf16raw*>(base + o), dst + j * 512);
+  };
+  auto issue = [&](int kind, int kt) { issue_piece(kind, kt, 0); issue_piece(kind, kt, 1); issue_piece(kind, kt, 2); issue_piece(kind, kt, 3); };
+  auto advance = [&](int kind) {
+    const bool isA = kind == 0 || kind == 3;
+    const int g = isA ? amap.grp : bmap.grp;
+    sp[kind] += isA ? step64_a : step64_b;
+    vld[kind] -= TP_BK;
+    if (g > 0) {
+      trm[kind] += TP_BK;
+      if (trm[kind] >= g) { trm[kind] -= g; sp[kind] += isA ? skipb_a : skipb_b; }
+      crs[kind] = g - trm[kind];
+    }
+  };
+  auto zero_tail = [&](int kt) {                  // rows >= last_valid of tile kt (this wave's own pieces)
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (prow0 + 8 * j >= last_valid)
+          *reinterpret_cast<uint4*>(lds + (kt & 1) * TP_BUF + kind * TP_REGION + wave * 2048 + j * 512 + lane * 8) =
+              make_uint4(0, 0, 0, 0);
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed fragment addressing inside a region (as in the ping-pong kernel): token row ks*16 + tr_row (+4), column c
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_sw = ((lane >> 3) & 1) << 2;
+  const int cl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const unsigned lds_b = (unsigned)(unsigned long)(tn_lds_char*)smem;
+  unsigned fa_addr[2], fb_addr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int cc = i * 32 + cl;                              // column inside the 64-column sub-block
+    const int off = tr_row * 64 + (((cc >> 3) ^ tr_sw) << 3) + (cc & 7);
+    fa_addr[i] = lds_b + 2u * (wr * 4096 + off);             // A regions: sub-block wr
+    fb_addr[i] = lds_b + 2u * (wc * 4096 + off);             // B regions: sub-block wc
+  }
+  // column sums (bias gradient) of the A regions of the K tiles kt % tiles2 == t2: thread -> sub-block tid >> 7,
+  // physical chunk tid & 7 of rows ((tid >> 3) & 15) + {0, 16, 32, 48}
+  constexpr bool want_cs = WANT_CS;
+  int cs_next = t2;
+  const int cs_sub = tid >> 7, cs_row = (tid >> 3) & 15, cs_pc = tid & 7;
+  const unsigned cs_addr = lds_b + 2u * (cs_sub * 4096 + cs_row * 64 + cs_pc * 8);
+  float cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u32x4 csv[4];
+#define TW_CS_READ(buf_, kind_)                                                                          \
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\t" \
+               "ds_read_b128 %3, %4 offset:6144"                                                         \
+               : "=&v"(csv[0]), "=&v"(csv[1]), "=&v"(csv[2]), "=&v"(csv[3])                             \
+               : "v"(cs_addr + 2u * ((buf_) * TP_BUF + (kind_) * TP_REGION)) : "memory")
+#define TW_CS_WAIT() { tp_lgkm0(); asm volatile("" : "+v"(csv[0]), "+v"(csv[1]), "+v"(csv[2]), "+v"(csv[3])); }
+#define TW_CS_ADD(cs_, q_)                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                        \
+    cs_[2 * j] += __uint_as_float(csv[q_][j] << 16);                                                     \
+    cs_[2 * j + 1] += __uint_as_float(csv[q_][j] & 0xffff0000u);                                         \
+  }
+// (the region kind and the 16-row step travel in the instruction's 16-bit offset field: one address register per operand
+// half and ring buffer instead of one per region, which hipcc hoists out of the loop and spills)
+#define TW_FRAG(dst_, addr_, kind_, ks_)                                                                 \
+  {                                                                                                      \
+    union { bf16x8 v; s16x4 h[2]; } u_;                                                                  \
+    u_.h[0] = tn_tr_read<(kind_) * 16384 + (ks_) * 2048>(addr_);                                         \
+    u_.h[1] = tn_tr_read<(kind_) * 16384 + (ks_) * 2048 + 512>(addr_); dst_ = u_.v;                      \
+  }
+#define TW_PIN(S_) asm volatile("" : "+v"(S_[0][0]), "+v"(S_[0][1]), "+v"(S_[0][2]), "+v"(S_[0][3]),     \
+                                     "+v"(S_[1][0]), "+v"(S_[1][1]), "+v"(S_[1][2]), "+v"(S_[1][3]))
+// the 256 accumulator registers live in the AGPR half of the file: without this the allocator splits their live ranges
+// between the two halves and moves whole tuples at the loop header
+#define TW_PIN_ACC()                                                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
+    asm volatile("" : "+a"(acc[i_][0]), "+a"(acc[i_][1]), "+a"(acc[i_][2]), "+a"(acc[i_][3]));
+#define TW_MF(i2_, j2_, ks_, AS_, i0_, BS_, j0_)                                                         \
+  acc[(i0_) + (i2_)][(j0_) + (j2_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS_[i2_][ks_], BS_[j2_][ks_], \
+                                                                            acc[(i0_) + (i2_)][(j0_) + (j2_)], 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+// 16 MFMAs, one hook behind each: consecutive MFMAs go to different accumulators (an accumulator comes round every
+// fourth instruction = 128 cycles, twice its 64-cycle latency)
+#define TW_MMA(AS_, i0_, BS_, j0_, H0_, H1_, H2_, H3_, H4_, H5_, H6_, H7_, H8_, H9_, H10_, H11_, H12_, H13_, H14_, H15_) \
+  __builtin_amdgcn_sched_barrier(0);                                                                     \
+  TW_MF(0, 0, 0, AS_, i0_, BS_, j0_) H0_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 0, 0, AS_, i0_, BS_, j0_) H1_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 1, 0, AS_, i0_, BS_, j0_) H2_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 1, 0, AS_, i0_, BS_, j0_) H3_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 0, 1, AS_, i0_, BS_, j0_) H4_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 0, 1, AS_, i0_, BS_, j0_) H5_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 1, 1, AS_, i0_, BS_, j0_) H6_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 1, 1, AS_, i0_, BS_, j0_) H7_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 0, 2, AS_, i0_, BS_, j0_) H8_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 0, 2, AS_, i0_, BS_, j0_) H9_;  __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 1, 2, AS_, i0_, BS_, j0_) H10_; __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 1, 2, AS_, i0_, BS_, j0_) H11_; __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 0, 3, AS_, i0_, BS_, j0_) H12_; __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 0, 3, AS_, i0_, BS_, j0_) H13_; __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(0, 1, 3, AS_, i0_, BS_, j0_) H14_; __builtin_amdgcn_sched_barrier(0);                            \
+  TW_MF(1, 1, 3, AS_, i0_, BS_, j0_) H15_; __builtin_amdgcn_sched_barrier(0);
+// end of a phase: the set just read is complete and its region released (lgkmcnt), this wave's pieces of the region the
+// next phase reads have landed (six regions were requested after it; in the last two tiles nothing more is requested:
+// everything), one barrier publishes both
+#define TW_END(n2_)                                                                                      \
+  tp_lgkm0();                                                                                            \
+  if (n2_) tn_wait_vmcnt<24>(); else tn_wait_vmcnt<0>();                                                 \
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa0[2][4], fa1[2][4], fbx[2][4], fby[2][4];
+  // prologue: all of K tiles 0 and 1 (the ring's eight slots), then the sets P1(0) multiplies, then A0(2) into the slot
+  // A0(0) has just left (the loop continues the request order with B0(2) in P1(0))
+  issue(0, 0); advance(0); issue(1, 0); advance(1); issue(2, 0); advance(2); issue(3, 0); advance(3);
+  issue(0, 1); advance(0); issue(1, 1); advance(1); issue(2, 1); advance(2); issue(3, 1); advance(3);
+  tn_wait_vmcnt<24>();                            // A0(0), B0(0) landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  {
+    const unsigned ra0 = fa_addr[0], ra1 = fa_addr[1], rb0 = fb_addr[0], rb1 = fb_addr[1];
+    TW_FRAG(fa0[0][0], ra0, 0, 0) TW_FRAG(fa0[1][0], ra1, 0, 0) TW_FRAG(fa0[0][1], ra0, 0, 1) TW_FRAG(fa0[1][1], ra1, 0, 1)
+    TW_FRAG(fa0[0][2], ra0, 0, 2) TW_FRAG(fa0[1][2], ra1, 0, 2) TW_FRAG(fa0[0][3], ra0, 0, 3) TW_FRAG(fa0[1][3], ra1, 0, 3)
+    TW_FRAG(fbx[0][0], rb0, 1, 0) TW_FRAG(fbx[1][0], rb1, 1, 0) TW_FRAG(fbx[0][1], rb0, 1, 1) TW_FRAG(fbx[1][1], rb1, 1, 1)
+    TW_FRAG(fbx[0][2], rb0, 1, 2) TW_FRAG(fbx[1][2], rb1, 1, 2) TW_FRAG(fbx[0][3], rb0, 1, 3) TW_FRAG(fbx[1][3], rb1, 1, 3)
+    tp_lgkm0();
+    if (want_cs && cs_next == 0) {
+      TW_CS_READ(0, 0);
+      TW_CS_WAIT();
+      TW_CS_ADD(cs0, 0) TW_CS_ADD(cs0, 1) TW_CS_ADD(cs0, 2) TW_CS_ADD(cs0, 3)
+    }
+    tn_wait_vmcnt<20>();                          // B1(0), which P1(0) reads, has landed too (five regions were requested after it)
+    __builtin_amdgcn_s_barrier();                 // ... and every wave has read A0(0): its slot takes A0(2)
+    TW_PIN(fa0); TW_PIN(fbx);
+    if (nk > 2) { issue(0, 2); advance(0); }
+  }
+  // X_ holds B0(kt), Y_ receives B1(kt) in P1 and B0(kt + 1) in P4: the two sets swap names every K tile
+#define TW_KTILE(kt_, X_, Y_)                                                                            \
+  {                                                                                                      \
+    const int kt = (kt_);                                                                                \
+    const int buf = kt & 1;                                                                              \
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk, n3 = kt + 3 < nk;                                     \
+    TW_PIN_ACC();                                                                                        \
+    /* P1: A0 x B0; reads B1(kt) -> Y_; requests B0(kt + 2) */                                           \
+    {                                                                                                    \
+      const unsigned r0_ = fb_addr[0] + 2u * (buf * TP_BUF), r1_ = fb_addr[1] + 2u * (buf * TP_BUF); \
+      TW_MMA(fa0, 0, X_, 0,                                                                              \
+             TW_FRAG(Y_[0][0], r0_, 2, 0), TW_FRAG(Y_[1][0], r1_, 2, 0), TW_FRAG(Y_[0][1], r0_, 2, 1), TW_FRAG(Y_[1][1], r1_, 2, 1), \
+             TW_FRAG(Y_[0][2], r0_, 2, 2), TW_FRAG(Y_[1][2], r1_, 2, 2), TW_FRAG(Y_[0][3], r0_, 2, 3), TW_FRAG(Y_[1][3], r1_, 2, 3), \
+             if (n2) issue_piece(1, kt + 2, 0), if (n2) issue_piece(1, kt + 2, 1), if (n2) issue_piece(1, kt + 2, 2), \
+             if (n2) issue_piece(1, kt + 2, 3), if (n2) advance(1), , , )                                \
+      TW_END(n2)                                                                                         \
+      TW_PIN(Y_);                                                                                        \
+    }                                                                                                    \
+    /* P2: A0 x B1; reads A1(kt) -> fa1 (+ its column sums); requests B1(kt + 2) */                      \
+    {                                                                                                    \
+      const unsigned r0_ = fa_addr[0] + 2u * (buf * TP_BUF), r1_ = fa_addr[1] + 2u * (buf * TP_BUF); \
+      const bool cs_ = want_cs && kt == cs_next;                                                         \
+      TW_MMA(fa0, 0, Y_, 2,                                                                              \
+             TW_FRAG(fa1[0][0], r0_, 3, 0), TW_FRAG(fa1[1][0], r1_, 3, 0), TW_FRAG(fa1[0][1], r0_, 3, 1), TW_FRAG(fa1[1][1], r1_, 3, 1), \
+             TW_FRAG(fa1[0][2], r0_, 3, 2), TW_FRAG(fa1[1][2], r1_, 3, 2), TW_FRAG(fa1[0][3], r0_, 3, 3), TW_FRAG(fa1[1][3], r1_, 3, 3), \
+             if (cs_) TW_CS_READ(buf, 3); if (n2) issue_piece(2, kt + 2, 0), if (n2) issue_piece(2, kt + 2, 1),  \
+             if (n2) issue_piece(2, kt + 2, 2), if (n2) issue_piece(2, kt + 2, 3),                       \
+             if (n2) advance(2); if (cs_) { TW_CS_WAIT() TW_CS_ADD(cs1, 0) }, if (cs_) { TW_CS_ADD(cs1, 1) }, \
+             if (cs_) { TW_CS_ADD(cs1, 2) }, if (cs_) { TW_CS_ADD(cs1, 3) })                             \
+      if (cs_) cs_next += tiles2;                                                                        \
+      if (!n2) {                                   /* the tile after this one is the last: wait for all of it, zero its tail */ \
+        tn_wait_vmcnt<0>();                                                                              \
+        if (n1 && last_valid < TP_BK) zero_tail(kt + 1);                                                 \
+      }                                                                                                  \
+      TW_END(n2)                                                                                         \
+      TW_PIN(fa1);                                                                                       \
+    }                                                                                                    \
+    /* P3: A1 x B1; reads A0(kt + 1) -> fa0 (+ its column sums); requests A1(kt + 2) */                  \
+    {                                                                                                    \
+      const unsigned r0_ = fa_addr[0] + 2u * ((buf ^ 1) * TP_BUF), r1_ = fa_addr[1] + 2u * ((buf ^ 1) * TP_BUF); \
+      const bool cs_ = want_cs && n1 && kt + 1 == cs_next;                                               \
+      TW_MMA(fa1, 2, Y_, 2,                                                                              \
+             TW_FRAG(fa0[0][0], r0_, 0, 0), TW_FRAG(fa0[1][0], r1_, 0, 0), TW_FRAG(fa0[0][1], r0_, 0, 1), \
+             TW_FRAG(fa0[1][1], r1_, 0, 1), TW_FRAG(fa0[0][2], r0_, 0, 2), TW_FRAG(fa0[1][2], r1_, 0, 2), \
+             TW_FRAG(fa0[0][3], r0_, 0, 3), TW_FRAG(fa0[1][3], r1_, 0, 3),                     \
+             if (cs_) TW_CS_READ(buf ^ 1, 0); if (n2) issue_piece(3, kt + 2, 0), if (n2) issue_piece(3, kt + 2, 1), \
+             if (n2) issue_piece(3, kt + 2, 2), if (n2) issue_piece(3, kt + 2, 3),                       \
+             if (n2) advance(3); if (cs_) { TW_CS_WAIT() TW_CS_ADD(cs0, 0) }, if (cs_) { TW_CS_ADD(cs0, 1) }, \
+             if (cs_) { TW_CS_ADD(cs0, 2) }, if (cs_) { TW_CS_ADD(cs0, 3) })                             \
+      TW_END(n2)                                                                                         \
+      TW_PIN(fa0);                                                                                       \
+    }                                                                                                    \
+    /* P4: A1 x B0; reads B0(kt + 1) -> Y_; requests A0(kt + 3) */                                       \
+    {                                                                                                    \
+      const unsigned r0_ = fb_addr[0] + 2u * ((buf ^ 1) * TP_BUF), r1_ = fb_addr[1] + 2u * ((buf ^ 1) * TP_BUF); \
+      TW_MMA(fa1, 2, X_, 0,                                                                              \
+             TW_FRAG(Y_[0][0], r0_, 1, 0), TW_FRAG(Y_[1][0], r1_, 1, 0), TW_FRAG(Y_[0][1], r0_, 1, 1), \
+             TW_FRAG(Y_[1][1], r1_, 1, 1), TW_FRAG(Y_[0][2], r0_, 1, 2), TW_FRAG(Y_[1][2], r1_, 1, 2), \
+             TW_FRAG(Y_[0][3], r0_, 1, 3), TW_FRAG(Y_[1][3], r1_, 1, 3),                       \
+             if (n3) issue_piece(0, kt + 3, 0), if (n3) issue_piece(0, kt + 3, 1), if (n3) issue_piece(0, kt + 3, 2), \
+             if (n3) issue_piece(0, kt + 3, 3), if (n3) advance(0), , , )                                \
+      TW_END(n3)                                   /* the sixth request behind B1(kt + 1) is this phase's A0(kt + 3) */ \
+      TW_PIN(Y_);                                                                                        \
+    }                                                                                                    \
+  }
+  // (pairs of K tiles, then the odd one: with `if (kt2 + 1 < nk)` around the second tile inside the loop the fragment sets that
+  // cross the back-edge come out of a merge and hipcc carries them through scratch)
+  int kt2 = 0;
+  for (; kt2 + 1 < nk; kt2 += 2) {
+    TW_KTILE(kt2, fbx, fby)
+    TW_KTILE(kt2 + 1, fby, fbx)
+  }
+  if (kt2 < nk) TW_KTILE(kt2, fbx, fby)
+#undef TW_KTILE
+#undef TW_PIN_ACC
+#undef TW_END
+#undef TW_MMA
+#undef TW_MF
+#undef TW_PIN
+#undef TW_FRAG
+  if (want_cs) {
+    // logical chunk of this thread = cs_pc ^ (((cs_row >> 1) & 1) << 2) (rows cs_row + 16 k share bit 1);
+    // sub-block s of A0 = tile columns s*128 + [0,64), of A1 = s*128 + 64 + [0,64)
+    float* red = reinterpret_cast<float*>(smem);            // [16][256] floats = 16 KB (the ring is free: last barrier above)
+    const int tc = cs_sub * 128 + (cs_pc ^ (((cs_row >> 1) & 1) << 2)) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[cs_row * 256 + tc + j] = cs0[j];
+      red[cs_row * 256 + tc + 64 + j] = cs1[j];
+    }
+    __syncthreads();
+    if (r0 + tid < out.N1) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += red[r * 256 + tid];
+      out.cslab[(long)split * out.slab_stride + (long)t2 * out.N1 + r0 + tid] = a;
+    }
+    __syncthreads();
+  }
+#undef TW_CS_READ
+#undef TW_CS_WAIT
+#undef TW_CS_ADD
+  float* stg = reinterpret_cast<float*>(smem + TP_RING_BYTES) + wave * 16 * TP_STG_LD;
+  float* dst = out.slab + (long)split * out.slab_stride;
+  // 16 rows x 64 contiguous columns per pass: rows r0 + wr*128 + mi*32 + half*16 + [0,16), columns c0 + jp*128 + wc*64 + [0,64)
+#define TW_EPI(mi_, half_, jp_)                                                                          \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);               /* one pass at a time: hoisted together, the 256 accumulator reads spill */ \
+    const int col = lane & 31, rhalf = (lane >> 5) * 4;                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int r = 0; r < 8; ++r)       \
+        stg[((r & 3) + 8 * (r >> 2) + rhalf) * TP_STG_LD + ni * 32 + col] = acc[mi_][2 * (jp_) + ni][8 * (half_) + r]; \
+    tp_lgkm0();                                                                                          \
+    __builtin_amdgcn_wave_barrier();                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                      \
+      const int rw = e * 8 + (lane >> 3);                                                                \
+      const int r = r0 + wr * 128 + (mi_) * 32 + (half_) * 16 + rw;                                      \
+      const int c = c0 + (jp_) * 128 + wc * 64 + (lane & 7) * 8;                                         \
+      if (r < out.N1 && c < out.N2) {                                                                    \
+        const float* sp_ = stg + rw * TP_STG_LD + (lane & 7) * 8;                                        \
+        float* d = dst + (long)r * out.N2 + c;                                                           \
+        *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(sp_);                           \
+        *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(sp_ + 4);                   \
+      }                                                                                                  \
+    }                                                                                                    \
+    tp_lgkm0();                                                                                          \
+    __builtin_amdgcn_wave_barrier();                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+  TW_EPI(0, 0, 0) TW_EPI(0, 1, 0) TW_EPI(1, 0, 0) TW_EPI(1, 1, 0) TW_EPI(2, 0, 0) TW_EPI(2, 1, 0) TW_EPI(3, 0, 0) TW_EPI(3, 1, 0)
+  TW_EPI(0, 0, 1) TW_EPI(0, 1, 1) TW_EPI(1, 0, 1) TW_EPI(1, 1, 1) TW_EPI(2, 0, 1) TW_EPI(2, 1, 1) TW_EPI(3, 0, 1) TW_EPI(3, 1, 1)
+#undef TW_EPI
+}
+
 static int tp_splits(int M, int N1, int N2) {
   const int tiles = cdiv(N1, 256) * cdiv(N2, 256);
   int s = 256 / tiles;                          // one workgroup per CU
@@ -1127,6 +1474,32 @@ extern "C" int vtx_gemm_tn(const vtx_gemm_tn_desc* d, void* stream) {
     // 768x768 219 / 208.  gemm_tn=pp256 / ring force one of them.
     const bool pp_fits = tp_eligible(d->M, d->N1, d->N2) && tp_map_ok(d->amap) && tp_map_ok(d->bmap);
     const bool want_pp = pp_fits && (o.gemm_tn == TN_PP256 || o.gemm_tn == TN_AUTO);
+    if (!safe && !nodma && pp_fits && o.gemm_tn == TN_W4) {
+      // one wave per SIMD, 128 x 128 wave tiles: the same tile / slab partition as the ping-pong kernel (bit-identical slabs)
+      const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
+      const int s_p = tp_splits(d->M, d->N1, d->N2);
+      const int m_per_p = (d->M / s_p) / TP_BK * TP_BK;
+      static std::atomic<unsigned long long> attr_set_w{0};
+      if (first_launch_on_device(attr_set_w))
+      {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_w4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_w4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+      }
+      if (m_per_p >= 2 * TP_BK) {
+        out.slab_stride = w_elems + (long)t2p * d->N1; out.cs_fold = t2p;
+        if (out.cslab)
+          hipLaunchKernelGGL(gemm_tn_bf16_w4_kernel<true>, dim3(t1p * t2p * s_p), dim3(TW_THREADS), TW_LDS_BYTES, st, d->M, m_per_p,
+                             (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out);
+        else
+          hipLaunchKernelGGL(gemm_tn_bf16_w4_kernel<false>, dim3(t1p * t2p * s_p), dim3(TW_THREADS), TW_LDS_BYTES, st, d->M, m_per_p,
+                             (const bf16raw*)d->A, d->lda, d->amap, (const bf16raw*)d->B, d->ldb, d->bmap, t2p, t1p * t2p, out);
+        int rc_w = check_launch("gemm_tn_w4");
+        if (rc_w) return rc_w;
+        if (!d->colsum) return launch_reduce_partials(out.slab, s_p, out.slab_stride, w_elems, d->C, d->accumulate, 1.0f, st);
+        return launch_reduce_partials(out.slab, s_p, out.slab_stride, w_elems + d->N1, d->C, d->accumulate, 1.0f, st,
+                                      d->colsum, w_elems, d->colsum_accumulate, t2p, d->N1);
+      }
+    }
     if (!safe && !nodma && want_pp) {
       const int t1p = cdiv(d->N1, 256), t2p = cdiv(d->N2, 256);
       const int s_p = tp_splits(d->M, d->N1, d->N2);
