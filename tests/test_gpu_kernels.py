@@ -571,7 +571,8 @@ def test_gemm_tn(dtype, M, N1, N2, vtx_opts):
 def test_gemm_tn_one_wave_per_simd_equals_ping_pong(M, N1, N2, cs, vtx_opts):
     """gemm_tn=w4 (round 5: four waves per workgroup, one per SIMD, 128 x 128 wave tiles, accumulators in AGPRs, fragment reads
     and LDS-DMA requests in the MFMA gaps) against gemm_tn=pp256: the same tile / slab partition, the same products summed in
-    the same order per accumulator -- weight gradients and fused bias-gradient column sums BIT-identical; and against float64.
+    the same order per accumulator -- weight gradients BIT-identical; the fused bias-gradient column sums associate differently
+    (four rows per thread and K tile instead of two: equal to fp32 rounding, 1e-6 of max); and against float64.
     Shapes: K-tile counts per slab odd / even / 2 (the pairs-then-odd-tile loop, the ragged last tile), token-row maps with the
     group boundary inside a K tile, 9 ... 36 output tiles."""
     from vtx import ops
@@ -588,7 +589,8 @@ def test_gemm_tn_one_wave_per_simd_equals_ping_pong(M, N1, N2, cs, vtx_opts):
     for C_w, cs_w in res['w4']:
         assert torch.equal(C_w, C_pp), f'w4 != pp256: max diff {(C_w - C_pp).abs().max().item():.3e}'
         if cs:
-            assert torch.equal(cs_w, cs_pp)
+            check(f'gemm_tn w4 colsum {M}x{N1}x{N2} vs pp256', cs_w.cpu(), cs_pp.cpu(), 1e-6)
+            assert torch.equal(cs_w, res['w4'][0][1]), 'run-to-run'
     if M <= 20000:
         check(f'gemm_tn w4 {M}x{N1}x{N2} vs f64', C_pp.cpu(), q(A, dtype).t() @ q(Bm, dtype), 2e-3)
     if N1 == 256:                                     # token-row maps (cls rows skipped) on both operands
@@ -599,7 +601,8 @@ def test_gemm_tn_one_wave_per_simd_equals_ping_pong(M, N1, N2, cs, vtx_opts):
         for v in ('pp256', 'w4'):
             vtx_opts('gemm_tn', v)
             out.append(ops.gemm_tn(dev(Xp, dtype), dev(Yp, dtype), Bp * Np, N1, N2, amap=tm, bmap=tm, want_colsum=True))
-        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        assert torch.equal(out[0][0], out[1][0])
+        check(f'gemm_tn w4 rowmaps colsum {M}x{N1}x{N2} vs pp256', out[1][1].cpu(), out[0][1].cpu(), 1e-6)
         if M <= 20000:
             check(f'gemm_tn w4 rowmaps {M}x{N1}x{N2} vs f64', out[1][0].cpu(),
                   q(Xp, dtype)[:, 1:].reshape(Bp * Np, N1).t() @ q(Yp, dtype)[:, 1:].reshape(Bp * Np, N2), 2e-3)

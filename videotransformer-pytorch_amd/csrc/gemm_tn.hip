@@ -938,7 +938,16 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
 // reader is done), a counted vmcnt (this wave's pieces of the region the next phase reads have landed: six regions = 24
 // requests were issued after it), and ONE barrier that publishes both facts.  Same LDS image, piece shapes, swizzle,
 // row-state machine and slab / column-sum outputs as the ping-pong kernel (a wave owns four pieces per region instead
-// of two); same products summed in the same order per accumulator: bit-identical slabs.
+// of two); same products summed in the same order per accumulator: bit-identical weight slabs (the column sums take four
+// rows per thread and K tile instead of two: equal to fp32 rounding).
+// MEASURED (round 5, interleaved A/B at 96 clips, tools/tn_compare.py, profiles/round5_tn_w4_ab.txt): 6 - 10 % SLOWER than the
+// ping-pong kernel on every training shape (768x3072 678 vs 634 us, 2304x768 519 vs 489, 768x768 197 vs 182; in the step 132.0
+// vs 129.7 ms).  3600 - 3700 cycles per K tile against the 2048 of its 64 MFMAs: what a lone wave cannot hide is the ISSUE cost
+// of the LDS-DMA requests (~60 cycles per 1-KiB piece among MFMAs, MI355X_MICROARCH.md; a K tile is 64 pieces whoever issues
+// them: 16 per wave here = ~960 cycles in which this SIMD's matrix pipe has no other client, 8 per wave in the ping-pong kernel
+// where the partner wave's MFMAs run meanwhile) plus ~10 cycles per transpose read.  The reads-per-MFMA argument was right and
+// beside the point: with LDS-DMA operands the two-waves-per-SIMD structure is what hides the request issue.  Kept as
+// gemm_tn=w4 (tested, never the default).
 constexpr int TW_THREADS = 256;
 constexpr int TW_LDS_BYTES = TP_RING_BYTES + 4 * 16 * TP_STG_LD * 4;
 
