@@ -249,7 +249,7 @@ def gemm_shape_table(per_shape, peak_tf):
     return rows
 
 
-def other_configs(dev, model8, head8, budget_s=20.0):
+def other_configs(dev, model8, head8, budget_s=40.0):
     """north_star's other shapes on the driver-witnessed line: 5-step mini-runs AFTER the timed region (never part of `value`),
     same step structure as the headline (bf16, buckets with direct gradients, fused optimizer, synthetic clips resident in HBM),
     under a hard wall-clock budget -- a configuration that would start beyond it is reported as skipped."""
@@ -312,6 +312,16 @@ def other_configs(dev, model8, head8, budget_s=20.0):
         classifier(*fresh(lambda: V.TimeSformer(num_frames=16))), 48, 16, FLOPS_FWD_BWD_PER_CLIP[16])
     run('ViViT-B fact_encoder, Conv3d tubelet 2, 16x3x224x224, bf16, fwd+CE+bwd+SGD (BASELINE configs[2])',
         classifier(*fresh(lambda: V.ViViT(num_frames=16))), 32, 16, 0.850e12)
+
+    # BASELINE configs[4]: TimeSformer-L (D 1024, 16 heads, 24 layers) on 96-frame clips -- 18 817 tokens per clip, every activation
+    # stored (no recompute: 2.1 GB per layer and clip, ~84 GB at 4 clips of the 288).  FLOPs per clip fwd+bwd: the Linears
+    # (17 D^2 per token and layer) + the attention cores (tools/other_configs.py::timesformer_l96).
+    tokens_l, D_l, layers_l = 196 * 96 + 1, 1024, 24
+    flops_l = 6.0 * tokens_l * (17 * D_l * D_l) * layers_l + 3.0 * layers_l * (4.0 * tokens_l * 96 * D_l + 4.0 * tokens_l * 197 * D_l)
+    run('TimeSformer-L divided_space_time (D 1024, 16 heads, 24 layers), 96x3x224x224, bf16, fwd+CE+bwd+SGD, all activations stored '
+        '(BASELINE configs[4], one GPU)',
+        classifier(*fresh(lambda: V.TimeSformer(num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=24))),
+        4, 96, flops_l, steps=3, warmup=1)
 
     def maskfeat(batch, frames):
         from vtx import ops

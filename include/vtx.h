@@ -288,9 +288,12 @@ int vtx_embed_table(int dtype, int P, int T, int D, const float* bias, const flo
 /* ------------------------------------------------------------------------ HOG
  * extract_hog_features (dataset.py:39-45) for F frames [F,H,W,3] uint8 ->
  * [F, H/16, W/16, 108] float64, bit-exact vs skimage 0.18.3 when `table` is
- * the |g_row| x |g_col| magnitude table built by vtx_hog_build_table (host
- * libm hypot, 256*256 doubles uploaded by the caller).  bins (optional):
- * [F,3,H,W] int32 orientation-bin ids. */
+ * the blob built by vtx_hog_build_table on the host and uploaded by the caller
+ * (vtx_hog_table_bytes() bytes: the 256*256 doubles hypot(|g_col|, |g_row|) of
+ * the host's libm, then 4096 words holding, per gradient pair, how many ulps
+ * that hypot lies from the correctly rounded square root -- the kernel computes
+ * the square root and applies the correction).  frames and out 16-byte aligned.
+ * bins (optional): [F,3,H,W] int32 orientation-bin ids. */
 size_t vtx_hog_table_bytes(void);
 int vtx_hog_build_table(double* host_table);
 int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table,

@@ -108,6 +108,8 @@ __global__ void probe_tr(unsigned short* out) {
   for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
 }
 
+int hog_selftest(int* bad_mag, int* bad_bin);     // hog.hip
+
 }  // namespace vtx
 
 using namespace vtx;
@@ -191,6 +193,14 @@ extern "C" int vtx_selftest(char* report, size_t report_bytes) {
     }
   }
   fails += bad != 0;
+  // ---- HOG: device magnitudes (correctly rounded sqrt + table correction) vs the host's hypot, integer bin rule vs float64
+  {
+    int bad_mag = -1, bad_bin = -1;
+    const int rc = hog_selftest(&bad_mag, &bad_bin);
+    say("hog magnitudes, all 65536 gradient pairs vs host hypot: %s (%d mismatches)\n", (rc || bad_mag) ? "FAIL" : "ok", bad_mag);
+    say("hog integer bin rule, all 261121 gradient pairs vs the float64 sign tests: %s (%d mismatches)\n", (rc || bad_bin) ? "FAIL" : "ok", bad_bin);
+    fails += (rc != 0 || bad_mag != 0) + (rc != 0 || bad_bin != 0);
+  }
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { say("device error: %s\n", hipGetErrorString(e)); ++fails; }
   hipFree(dA); hipFree(dB); hipFree(dD); hipFree(dT);

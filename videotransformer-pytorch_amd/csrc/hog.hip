@@ -4,28 +4,44 @@
 // pixels_per_cell=(8,8), cells_per_block=(1,1), block_norm='L2') per channel.
 // Bit-exact contract (see oracle/hog_oracle.py for the derivation):
 //   * gradients are integer central differences (0 on the image border);
-//   * the orientation bin is decided by exact sign tests against the eight
-//     interior bin boundaries (integer gradients only ever touch the 0-degree
-//     boundary), so no atan2 is evaluated;
-//   * magnitude = libm hypot(g_col, g_row), taken from a host-built 256x256
-//     table indexed by |g_row|,|g_col| (libm hypot is not always the correctly
-//     rounded sqrt, and bit-exactness vs skimage needs the same function);
-//   * per (cell, bin): the 64 magnitudes are accumulated in row-major order into
-//     a float32 accumulator with double adds, divided by 64 in float32;
+//   * the orientation bin is decided without atan2 and without floating point: skimage's interval test equals the eight
+//     sign tests  g_row cos(20k) - g_col sin(20k) >= 0  (proven for all 261 121 integer gradient pairs, oracle tests), and
+//     those equal  |g_col| <= floor(g_row cot(20j))  for j = 1..4 with the sign of g_col choosing the half -- four
+//     fixed-point products (g cot is never within 2.6e-4 of an integer for g <= 255: 16 fraction bits decide it);
+//     vtx_selftest checks the integer rule against the double rule for every pair ON THE DEVICE;
+//   * magnitude = libm hypot(g_col, g_row) of the HOST (what numpy calls): for the 65 536 integer pairs it differs from
+//     the correctly rounded sqrt(g_row^2 + g_col^2) in 300 entries by one ulp (glibc 2.35), so the kernel computes the
+//     correctly rounded square root (device sqrt) and adds a 2-bit correction looked up in a 16-KB table that
+//     vtx_hog_build_table derives from the host's hypot (round 4 gathered the 512-KB double table per pixel: the
+//     vector L1 fills, not the arithmetic, bounded it); vtx_selftest compares all 65 536 magnitudes with the host table;
+//   * per (cell, bin): the magnitudes of that bin's pixels are accumulated in row-major order into a float32
+//     accumulator with double adds, divided by 64 in float32 (pixels with magnitude 0 leave the accumulator unchanged);
 //   * per cell: L2 norm in float64 with numpy's pairwise order for 9 terms.
-// HBM-bound: 150 528 B read + 169 344 B written per 224x224 frame.
-// One workgroup per (frame, channel, cell row): 28 cells x 9 bins = 252 threads.
+// HBM-bound by bytes: 150 528 B read + 169 344 B written per 224x224 frame.
+//
+// Round 5 kernel.  One persistent workgroup per (frame, cell row) item for ALL THREE channels: the ten pixel rows of a
+// strip are one contiguous 30 W-byte block of the interleaved RGB frame, fetched with 16-byte loads (every byte once per
+// strip; round 4: one workgroup per channel, stride-3 byte loads, each row three times).  Per channel: (A) a thread per
+// pixel column walks the eight rows -- gradient, integer bin, magnitude -> LDS, and ONE LDS atomic OR that sets the
+// pixel's bit in the 64-bit mask of its (cell, bin); (B) a thread per (cell, bin) walks only the SET bits of its mask in
+// ascending (= row-major) order -- on average 7 double adds instead of 64 compare-and-maybe-add steps; then (C) the
+// norms, and the 27 features of a cell leave as 16-byte stores (two horizontally adjacent cells = 432 contiguous bytes).
 #include <math.h>
+#include <string.h>
+#include <vector>
 #include "common.h"
 
 namespace vtx {
+
+constexpr int HOG_EXC_WORDS = 4096;          // 65 536 gradient pairs x 2 bits: 0 = hypot is the rounded sqrt, 1 = one ulp above, 3 = one below
 
 __constant__ double HOG_BC[8] = {0.93969262078590838, 0.76604444311897804, 0.5, 0.17364817766693035,
                                  -0.17364817766693035, -0.5, -0.76604444311897804, -0.93969262078590838};
 __constant__ double HOG_BS[8] = {0.34202014332566873, 0.64278760968653933, 0.8660254037844386, 0.98480775301220806,
                                  0.98480775301220806, 0.8660254037844386, 0.64278760968653933, 0.34202014332566873};
 
-__device__ inline int hog_bin(int gr, int gc) {
+// the eight sign tests in float64 (round 1 - 4 kernel; kept as the device-side cross-check of the integer rule)
+__device__ inline int hog_bin_f64(int gr, int gc) {
   if (gr == 0 && gc == 0) return 0;
   if (gr < 0 || (gr == 0 && gc < 0)) { gr = -gr; gc = -gc; }
   int b = 0;
@@ -34,59 +50,132 @@ __device__ inline int hog_bin(int gr, int gc) {
   return b;
 }
 
-// frames [F,H,W,3] u8; grid = (H/8 cell rows, 3 channels, F); block = 256 threads.
-__global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ frames, int H, int W,
-                                                  const double* __restrict__ table, double* __restrict__ out,
+// integer rule: with (g, c) = (g_row, g_col) flipped into the upper half plane, the orientation is at least 20 j degrees
+// iff |c| <= floor(g cot(20 j)) on the c >= 0 side (bins 0..4), and the mirror image on the c < 0 side (bins 4..8).
+// floor(g cot) = (g * round(cot * 2^16)) >> 16 for every g in 0..255 (checked offline and by vtx_selftest).
+__device__ inline int hog_bin(int gr, int gc) {
+  const bool flip = gr < 0 || (gr == 0 && gc < 0);
+  const int g = flip ? -gr : gr, c = flip ? -gc : gc;
+  const int a = c < 0 ? -c : c;
+  const int cnt = (a <= ((g * 180059) >> 16) ? 1 : 0) + (a <= ((g * 78103) >> 16) ? 1 : 0) +
+                  (a <= ((g * 37837) >> 16) ? 1 : 0) + (a <= ((g * 11556) >> 16) ? 1 : 0);
+  const int b = c >= 0 ? cnt : 8 - cnt;
+  return (gr | gc) == 0 ? 0 : b;
+}
+
+// host hypot(ac, ar) for 0 <= ar, ac <= 255: correctly rounded sqrt of the exact integer ar^2 + ac^2, moved by the
+// table's correction (`word` = exc[(ar * 256 + ac) >> 4])
+__device__ inline double hog_mag(int ar, int ac, unsigned word) {
+  const int idx = ar * 256 + ac;
+  const double m = sqrt((double)(ar * ar + ac * ac));
+  const int delta = ((int)(word << (30 - 2 * (idx & 15)))) >> 30;          // 2-bit field, sign-extended: 0, +1, -1
+  return __longlong_as_double(__double_as_longlong(m) + (long long)delta);
+}
+
+// frames [F,H,W,3] u8; grid = persistent workgroups over the F * (H/8) strips; block = 256 threads.
+__global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ frames, int F, int H, int W,
+                                                  const uint32_t* __restrict__ exc, double* __restrict__ out,
                                                   int32_t* __restrict__ bins) {
   extern __shared__ __attribute__((aligned(16))) char hsm[];
-  const int nc = W / 8;
-  // LDS: pixels of rows [y0-1, y0+8] for this channel (10 x W u8), then per-pixel bin (u8) and magnitude (f64)
-  uint8_t* px = reinterpret_cast<uint8_t*>(hsm);                       // [10][W]
-  double* mag = reinterpret_cast<double*>(hsm + ((10 * W + 15) & ~15)); // [8][W]
-  uint8_t* pb = reinterpret_cast<uint8_t*>(mag + 8 * W);               // [8][W]
-  double* hist = reinterpret_cast<double*>(pb + ((8 * W + 15) & ~15)); // [nc][9]
-  const int cr = blockIdx.x, ch = blockIdx.y, f = blockIdx.z;
-  const int y0 = cr * 8;
-  const uint8_t* img = frames + (long)f * H * W * 3;
-  for (int i = threadIdx.x; i < 10 * W; i += blockDim.x) {
-    const int ry = i / W, x = i - ry * W;
-    const int y = y0 - 1 + ry;
-    px[i] = (y >= 0 && y < H) ? img[((long)y * W + x) * 3 + ch] : 0;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 8 * W; i += blockDim.x) {
-    const int ry = i / W, x = i - ry * W;
-    const int y = y0 + ry;
-    int gr = 0, gc = 0;
-    if (y > 0 && y < H - 1) gr = (int)px[(ry + 2) * W + x] - (int)px[ry * W + x];
-    if (x > 0 && x < W - 1) gc = (int)px[(ry + 1) * W + x + 1] - (int)px[(ry + 1) * W + x - 1];
-    const int b = hog_bin(gr, gc);
-    pb[i] = (uint8_t)b;
-    mag[i] = table[abs(gr) * 256 + abs(gc)];
-    if (bins) bins[(((long)f * 3 + ch) * H + y) * W + x] = b;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nc * 9; i += blockDim.x) {
-    const int cc = i / 9, ob = i - cc * 9;
-    float tot = 0.0f;
-    for (int py = 0; py < 8; ++py)
-      for (int pxx = 0; pxx < 8; ++pxx) {
-        const int o = py * W + cc * 8 + pxx;
-        if (pb[o] == ob) tot = (float)((double)tot + mag[o]);
+  const int nc = W / 8, W3 = 3 * W;
+  uint32_t* excs = reinterpret_cast<uint32_t*>(hsm);                                    // [4096]
+  uint8_t* px = reinterpret_cast<uint8_t*>(hsm + HOG_EXC_WORDS * 4);                    // [10][3 W]  (30 W bytes, W % 16 == 0)
+  double* mag = reinterpret_cast<double*>(px + 10 * W3);                                // [8][W]
+  uint32_t* msk = reinterpret_cast<uint32_t*>(mag + 8 * W);                             // [nc][9][2]
+  double* hist = reinterpret_cast<double*>(msk + nc * 18);                              // [nc][27]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < HOG_EXC_WORDS; i += 256) excs[i] = exc[i];
+  const int strips = H / 8;
+  const long items = (long)F * strips;
+  for (long item = blockIdx.x; item < items; item += gridDim.x) {
+    const int f = (int)(item / strips), cr = (int)(item - (long)f * strips);
+    const int y0 = cr * 8;
+    const uint8_t* img = frames + (long)f * H * W3;
+    __syncthreads();                                 // the previous strip's feature stores have read hist; excs is in place
+    // rows y0-1 .. y0+8: one contiguous block of the frame, 16 bytes per load; rows outside the frame read as 0
+    {
+      const long first = (long)(y0 - 1) * W3, last = (long)H * W3;
+      for (int v = tid; v < (10 * W3) / 16; v += 256) {
+        const long g0 = first + (long)v * 16;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (g0 >= 0 && g0 < last) val = *reinterpret_cast<const uint4*>(img + g0);
+        *reinterpret_cast<uint4*>(px + v * 16) = val;
       }
-    hist[i] = (double)(tot / 64.0f);
-  }
-  __syncthreads();
-  for (int cc = threadIdx.x; cc < nc; cc += blockDim.x) {
-    const double* h = hist + cc * 9;
-    double s = ((h[0] * h[0] + h[1] * h[1]) + (h[2] * h[2] + h[3] * h[3])) +
-               ((h[4] * h[4] + h[5] * h[5]) + (h[6] * h[6] + h[7] * h[7]));
-    s += h[8] * h[8];
-    const double nrm = sqrt(s + 1e-5 * 1e-5);
-    const int ph = cr >> 1, dh = cr & 1, pw = cc >> 1, dw = cc & 1;
-    double* o = out + (((long)f * (H / 16) + ph) * (W / 16) + pw) * 108 + dh * 54 + dw * 27 + ch * 9;
+    }
+    for (int ch = 0; ch < 3; ++ch) {
+      for (int i = tid; i < nc * 18; i += 256) msk[i] = 0u;
+      __syncthreads();                               // pixels (ch 0) / masks cleared; phase B of the previous channel is done
+      // (A) one pixel column per thread, eight rows
+      for (int x = tid; x < W; x += 256) {
+        const bool xin = x > 0 && x < W - 1;
+        const int xo = 3 * x + ch;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[k] = h[k] / nrm;
+        for (int ry = 0; ry < 8; ++ry) {
+          const int y = y0 + ry;
+          int gr = 0, gc = 0;
+          if (y > 0 && y < H - 1) gr = (int)px[(ry + 2) * W3 + xo] - (int)px[ry * W3 + xo];
+          if (xin) gc = (int)px[(ry + 1) * W3 + xo + 3] - (int)px[(ry + 1) * W3 + xo - 3];
+          const int b = hog_bin(gr, gc);
+          const int ar = gr < 0 ? -gr : gr, ac = gc < 0 ? -gc : gc;
+          const double m = hog_mag(ar, ac, excs[(ar * 256 + ac) >> 4]);
+          mag[ry * W + x] = m;
+          if ((gr | gc) != 0) atomicOr(&msk[((x >> 3) * 9 + b) * 2 + (ry >> 2)], 1u << ((ry & 3) * 8 + (x & 7)));
+          if (bins) bins[(((long)f * 3 + ch) * H + y) * W + x] = b;
+        }
+      }
+      __syncthreads();
+      // (B) one (cell, bin) per thread: the set bits of its mask in ascending order = the cell's pixels of that bin, row-major
+      for (int i = tid; i < nc * 9; i += 256) {
+        const int cc = i / 9, ob = i - cc * 9;
+        uint32_t m0 = msk[i * 2], m1 = msk[i * 2 + 1];
+        const double* mg = mag + cc * 8;
+        float tot = 0.0f;
+        while (m0) {
+          const int p = __builtin_ctz(m0);
+          m0 &= m0 - 1;
+          tot = (float)((double)tot + mg[(p >> 3) * W + (p & 7)]);
+        }
+        while (m1) {
+          const int p = __builtin_ctz(m1);
+          m1 &= m1 - 1;
+          tot = (float)((double)tot + mg[(4 + (p >> 3)) * W + (p & 7)]);
+        }
+        hist[cc * 27 + ch * 9 + ob] = (double)(tot / 64.0f);
+      }
+      __syncthreads();
+    }
+    // (C) L2 norm per (cell, channel), in place
+    for (int i = tid; i < nc * 3; i += 256) {
+      double* h = hist + (i / 3) * 27 + (i % 3) * 9;
+      double s = ((h[0] * h[0] + h[1] * h[1]) + (h[2] * h[2] + h[3] * h[3])) +
+                 ((h[4] * h[4] + h[5] * h[5]) + (h[6] * h[6] + h[7] * h[7]));
+      s += h[8] * h[8];
+      const double nrm = sqrt(s + 1e-5 * 1e-5);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) h[k] = h[k] / nrm;
+    }
+    __syncthreads();
+    // features: cells 2 pw and 2 pw + 1 of this strip are 54 contiguous doubles of out (dw = 0, 1 at dh = cr & 1)
+    {
+      const int ph = cr >> 1, dh = cr & 1;
+      double* orow = out + (((long)f * (H / 16) + ph) * (W / 16)) * 108 + dh * 54;
+      for (int i = tid; i < (nc / 2) * 27; i += 256) {
+        const int pw = i / 27, j = i - pw * 27;
+        *reinterpret_cast<double2*>(orow + (long)pw * 108 + 2 * j) = *reinterpret_cast<const double2*>(hist + pw * 54 + 2 * j);
+      }
+    }
+  }
+}
+
+// vtx_selftest: every gradient pair through the device functions above -- magnitudes [256*256] and both bin rules [511*511]
+__global__ void hog_probe_kernel(const uint32_t* __restrict__ exc, double* __restrict__ mags, int* __restrict__ bin_int,
+                                 int* __restrict__ bin_f64) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 65536) mags[i] = hog_mag(i >> 8, i & 255, exc[i >> 4]);
+  if (i < 511 * 511) {
+    const int gr = i / 511 - 255, gc = i % 511 - 255;
+    bin_int[i] = hog_bin(gr, gc);
+    bin_f64[i] = hog_bin_f64(gr, gc);
   }
 }
 
@@ -210,14 +299,53 @@ __global__ __launch_bounds__(256) void mf_loss_bwd_kernel(long rows, int Tq, int
 
 using namespace vtx;
 
-extern "C" size_t vtx_hog_table_bytes(void) { return (size_t)256 * 256 * sizeof(double); }
+extern "C" size_t vtx_hog_table_bytes(void) { return (size_t)256 * 256 * sizeof(double) + (size_t)HOG_EXC_WORDS * sizeof(uint32_t); }
 
+// [65 536 doubles: the host's hypot(c, r)] [4096 words: per pair, 2 bits = hypot minus the correctly rounded sqrt(r^2 + c^2) in ulps]
 extern "C" int vtx_hog_build_table(double* host_table) {
   VTX_REQUIRE(host_table != nullptr, VTX_EINVAL, "hog_build_table: null pointer");
+  uint32_t* exc = reinterpret_cast<uint32_t*>(host_table + 256 * 256);
+  for (int w = 0; w < HOG_EXC_WORDS; ++w) exc[w] = 0u;
   for (int r = 0; r < 256; ++r)
-    for (int c = 0; c < 256; ++c) host_table[r * 256 + c] = hypot((double)c, (double)r);
+    for (int c = 0; c < 256; ++c) {
+      const double h = hypot((double)c, (double)r);
+      const double q = sqrt((double)(r * r + c * c));          // the integer is exact, the host square root correctly rounded
+      host_table[r * 256 + c] = h;
+      long long hb, qb;
+      memcpy(&hb, &h, 8);
+      memcpy(&qb, &q, 8);
+      const long long d = hb - qb;
+      VTX_REQUIRE(d >= -1 && d <= 1, VTX_EINVAL, "hog_build_table: hypot(%d, %d) is %lld ulps from the rounded square root", c, r, d);
+      const int idx = r * 256 + c;
+      exc[idx >> 4] |= (uint32_t)(d & 3) << (2 * (idx & 15));
+    }
   return VTX_OK;
 }
+
+namespace vtx {
+// part of vtx_selftest (api.hip): 0 = the device reproduces the host's hypot for all 65 536 gradient pairs and the integer
+// bin rule equals the float64 sign tests for all 511 x 511 pairs
+int hog_selftest(int* bad_mag, int* bad_bin) {
+  std::vector<double> tab(vtx_hog_table_bytes() / 8);
+  if (vtx_hog_build_table(tab.data()) != VTX_OK) return -1;
+  uint32_t* d_exc = nullptr; double* d_mag = nullptr; int *d_bi = nullptr, *d_bf = nullptr;
+  const int NB = 511 * 511;
+  if (hipMalloc(&d_exc, HOG_EXC_WORDS * 4) != hipSuccess || hipMalloc(&d_mag, 65536 * 8) != hipSuccess ||
+      hipMalloc(&d_bi, NB * 4) != hipSuccess || hipMalloc(&d_bf, NB * 4) != hipSuccess) return -1;
+  hipMemcpy(d_exc, tab.data() + 65536, HOG_EXC_WORDS * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(hog_probe_kernel, dim3((NB + 255) / 256), dim3(256), 0, 0, d_exc, d_mag, d_bi, d_bf);
+  std::vector<double> mags(65536);
+  std::vector<int> bi(NB), bf(NB);
+  hipMemcpy(mags.data(), d_mag, 65536 * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(bi.data(), d_bi, NB * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(bf.data(), d_bf, NB * 4, hipMemcpyDeviceToHost);
+  *bad_mag = 0; *bad_bin = 0;
+  for (int i = 0; i < 65536; ++i) *bad_mag += memcmp(&mags[i], &tab[i], 8) != 0;
+  for (int i = 0; i < NB; ++i) *bad_bin += bi[i] != bf[i];
+  hipFree(d_exc); hipFree(d_mag); hipFree(d_bi); hipFree(d_bf);
+  return 0;
+}
+}  // namespace vtx
 
 extern "C" int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table, double* out, int32_t* bins,
                            void* stream) {
@@ -225,9 +353,17 @@ extern "C" int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const dou
               "hog_fwd: H=%d, W=%d must be multiples of 16 (W <= 1024)", H, W);
   if (F == 0) return VTX_OK;                       // empty batch: nothing to do (pointers may be null)
   VTX_REQUIRE(frames && table && out, VTX_EINVAL, "hog_fwd: null pointer");
-  const size_t lds = ((10 * W + 15) & ~15) + (size_t)8 * W * 8 + ((8 * W + 15) & ~15) + (size_t)(W / 8) * 9 * 8;
-  dim3 grid(H / 8, 3, F), block(256);
-  hipLaunchKernelGGL(hog_kernel, grid, block, lds, as_stream(stream), frames, H, W, table, out, bins);
+  VTX_REQUIRE(aligned16(frames) && aligned16(out), VTX_EALIGN, "hog_fwd: frames and out must be 16-byte aligned");
+  const uint32_t* exc = reinterpret_cast<const uint32_t*>(table + 256 * 256);   // the correction words behind the 65 536 doubles
+  const size_t lds = (size_t)HOG_EXC_WORDS * 4 + (size_t)30 * W + (size_t)8 * W * 8 + (size_t)(W / 8) * 18 * 4 + (size_t)(W / 8) * 27 * 8;
+  static std::atomic<unsigned long long> attr_set{0};
+  if (first_launch_on_device(attr_set))
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // persistent: as many workgroups as fit at once (LDS-limited), each walks strips with stride gridDim
+  const long items = (long)F * (H / 8);
+  long per_cu = (long)(160 * 1024) / (long)lds; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
+  long grid = per_cu * device_cus(); if (grid > items) grid = items;
+  hipLaunchKernelGGL(hog_kernel, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), frames, F, H, W, exc, out, bins);
   return check_launch("hog_fwd");
 }
 

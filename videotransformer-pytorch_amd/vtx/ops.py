@@ -542,7 +542,7 @@ _hog_tables = {}
 def hog_table(device):
     key = str(device)
     if key not in _hog_tables:
-        host = torch.empty(256 * 256, dtype=torch.float64)
+        host = torch.empty(_lib.load().vtx_hog_table_bytes() // 8, dtype=torch.float64)     # magnitudes + the correction words
         call('vtx_hog_build_table', host.data_ptr())
         _hog_tables[key] = host.to(device)
     return _hog_tables[key]
