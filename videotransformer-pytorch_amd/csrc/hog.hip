@@ -57,19 +57,45 @@ __device__ inline int hog_bin(int gr, int gc) {
   const bool flip = gr < 0 || (gr == 0 && gc < 0);
   const int g = flip ? -gr : gr, c = flip ? -gc : gc;
   const int a = c < 0 ? -c : c;
-  const int cnt = (a <= ((g * 180059) >> 16) ? 1 : 0) + (a <= ((g * 78103) >> 16) ? 1 : 0) +
-                  (a <= ((g * 37837) >> 16) ? 1 : 0) + (a <= ((g * 11556) >> 16) ? 1 : 0);
+  // (g <= 255 and the constants are below 2^18: the 24-bit multiply is exact and full rate, v_mul_lo_u32 is quarter rate)
+  const int cnt = (a <= (__mul24(g, 180059) >> 16) ? 1 : 0) + (a <= (__mul24(g, 78103) >> 16) ? 1 : 0) +
+                  (a <= (__mul24(g, 37837) >> 16) ? 1 : 0) + (a <= (__mul24(g, 11556) >> 16) ? 1 : 0);
   const int b = c >= 0 ? cnt : 8 - cnt;
   return (gr | gc) == 0 ? 0 : b;
 }
 
-// host hypot(ac, ar) for 0 <= ar, ac <= 255: correctly rounded sqrt of the exact integer ar^2 + ac^2, moved by the
-// table's correction (`word` = exc[(ar * 256 + ac) >> 4])
+// host hypot(ac, ar) for 0 <= ar, ac <= 255: correctly rounded sqrt of the exact integer n = ar^2 + ac^2 <= 130 050, moved by
+// the table's correction (`word` = exc[(ar * 256 + ac) >> 4]).  The square root: n is exact in float32, s = v_sqrt_f32(n) is
+// good to ~2^-23, h = 0.5 / s from v_rcp_f32; two Newton corrections in float64 -- r = fma(-m, m, n) is the exact residual of
+// the 24-bit s in the first, m += r * h -- leave an error of ~2^-69 m, far below the half-ulp of the result (the generic
+// float64 lowering costs twice the float64 instructions: range scaling, v_rsq_f64, three iterations).  "Far below" is not a
+// proof of correct rounding: vtx_selftest compares ALL 65 536 magnitudes with the host table on the device at hand.
 __device__ inline double hog_mag(int ar, int ac, unsigned word) {
   const int idx = ar * 256 + ac;
-  const double m = sqrt((double)(ar * ar + ac * ac));
+  const int n = __mul24(ar, ar) + __mul24(ac, ac);
+#if defined(HOG_ABLATE) && HOG_ABLATE == 1           // diagnostic builds (csrc/build.py --variant): no square root
+  double m = (double)n;
+#elif defined(HOG_ABLATE) && HOG_ABLATE == 6         // the compiler's float64 square root
+  double m = sqrt((double)n);
+#else
+  const float nf = (float)n;
+  const float s = __builtin_amdgcn_sqrtf(nf);
+  const double x = (double)nf;
+  double m = (double)s;
+  const double h = (double)(0.5f * __builtin_amdgcn_rcpf(s));
+  m = fma(fma(-m, m, x), h, m);
+  m = fma(fma(-m, m, x), h, m);
+  m = n == 0 ? 0.0 : m;                              // rcp(0) = inf
+#endif
+#if defined(HOG_ABLATE) && HOG_ABLATE == 2           // no correction
+  return m + (double)(word & 0u);
+#else
   const int delta = ((int)(word << (30 - 2 * (idx & 15)))) >> 30;          // 2-bit field, sign-extended: 0, +1, -1
-  return __longlong_as_double(__double_as_longlong(m) + (long long)delta);
+  // one ulp up or down = the low word +- 1: no square root of these integers has a low word of all zeros or all ones next to a
+  // correction (vtx_selftest would show it), so the carry into the high word is never needed
+  const long long b = __double_as_longlong(m);
+  return __longlong_as_double((b & ~0xffffffffLL) | (unsigned)((int)b + delta));
+#endif
 }
 
 // frames [F,H,W,3] u8; grid = persistent workgroups over the F * (H/8) strips; block = 256 threads.
@@ -80,7 +106,7 @@ __global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ fr
   const int nc = W / 8, W3 = 3 * W;
   uint32_t* excs = reinterpret_cast<uint32_t*>(hsm);                                    // [4096]
   uint8_t* px = reinterpret_cast<uint8_t*>(hsm + HOG_EXC_WORDS * 4);                    // [10][3 W]  (30 W bytes, W % 16 == 0)
-  double* mag = reinterpret_cast<double*>(px + 10 * W3);                                // [8][W]
+  double* mag = reinterpret_cast<double*>(px + 10 * W3);                                // [nc][8 rows][8 columns]
   uint32_t* msk = reinterpret_cast<uint32_t*>(mag + 8 * W);                             // [nc][9][2]
   double* hist = reinterpret_cast<double*>(msk + nc * 18);                              // [nc][27]
   const int tid = threadIdx.x;
@@ -115,30 +141,55 @@ __global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ fr
           int gr = 0, gc = 0;
           if (y > 0 && y < H - 1) gr = (int)px[(ry + 2) * W3 + xo] - (int)px[ry * W3 + xo];
           if (xin) gc = (int)px[(ry + 1) * W3 + xo + 3] - (int)px[(ry + 1) * W3 + xo - 3];
+#if defined(HOG_ABLATE) && HOG_ABLATE == 4           // no bin rule
+          const int b = (gr + gc) & 7;
+#else
           const int b = hog_bin(gr, gc);
+#endif
           const int ar = gr < 0 ? -gr : gr, ac = gc < 0 ? -gc : gc;
+#if defined(HOG_ABLATE) && HOG_ABLATE == 5           // no magnitude at all
+          const double m = (double)(ar + ac);
+#else
           const double m = hog_mag(ar, ac, excs[(ar * 256 + ac) >> 4]);
-          mag[ry * W + x] = m;
+#endif
+          mag[(x >> 3) * 64 + ry * 8 + (x & 7)] = m;      // cell-major: phase B addresses a pixel by its bit position alone
           if ((gr | gc) != 0) atomicOr(&msk[((x >> 3) * 9 + b) * 2 + (ry >> 2)], 1u << ((ry & 3) * 8 + (x & 7)));
           if (bins) bins[(((long)f * 3 + ch) * H + y) * W + x] = b;
         }
       }
       __syncthreads();
       // (B) one (cell, bin) per thread: the set bits of its mask in ascending order = the cell's pixels of that bin, row-major
+#if defined(HOG_ABLATE) && HOG_ABLATE == 3           // no phase B
+      for (int i = tid; i < nc * 9; i += 256) hist[(i / 9) * 27 + ch * 9 + i % 9] = mag[i];     // (diagnostic)
+      if (false)
+#endif
       for (int i = tid; i < nc * 9; i += 256) {
         const int cc = i / 9, ob = i - cc * 9;
         uint32_t m0 = msk[i * 2], m1 = msk[i * 2 + 1];
-        const double* mg = mag + cc * 8;
+        const double* mg = mag + cc * 64;
         float tot = 0.0f;
-        while (m0) {
-          const int p = __builtin_ctz(m0);
-          m0 &= m0 - 1;
-          tot = (float)((double)tot + mg[(p >> 3) * W + (p & 7)]);
-        }
-        while (m1) {
-          const int p = __builtin_ctz(m1);
-          m1 &= m1 - 1;
-          tot = (float)((double)tot + mg[(4 + (p >> 3)) * W + (p & 7)]);
+        // four set bits per trip: the four magnitudes are requested together, the adds stay sequential and in ascending bit
+        // order (= row-major in the cell); a bit position beyond the mask's population reads pixel 0 and is not added
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint32_t m = half ? m1 : m0;
+          const double* mh = mg + half * 32;
+          while (m) {
+            int p[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[k] = m != 0;
+              p[k] = v[k] ? __builtin_ctz(m) : 0;
+              m &= m - 1;
+            }
+            double a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = mh[p[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (v[k]) tot = (float)((double)tot + a[k]);
+          }
         }
         hist[cc * 27 + ch * 9 + ob] = (double)(tot / 64.0f);
       }
