@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 FLOPS_FWD_BWD_PER_CLIP = {8: 1.175e12, 16: 2.352e12, 2: 0.2937e12}
 PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0         # TB/s (spec; ~6.3 TB/s is what a streaming copy reaches)
-PMC_ROUNDS = ('round4_', 'round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
+PMC_ROUNDS = ('round5_', 'round4_', 'round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
 
 
 def parse():
