@@ -569,14 +569,17 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_nt_bf16_pp_kernel(
 // HW_: inside the fence right behind the section's request (waits of a rolling pass); HB_: behind the fence, in the same
 // scheduling region as the section's remaining six MFMAs -- the compiler mixes it into their shadow
 #define PP_MMA(i0_, j_, fb_, ISSUE_) PP_MMA_H(i0_, j_, fb_, ISSUE_, , )
+#ifndef VTX_PP_PRIO
+#define VTX_PP_PRIO 1   // 1 = s_setprio 1 around every MFMA section (default); experiments: 0 = none, 3 = the load sections at 1
+#endif
 #define PP_MMA_H(i0_, j_, fb_, ISSUE_, HW_, HB_)                                                       \
-  __builtin_amdgcn_s_setprio(1);                                                                       \
+  if (VTX_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1); else if (VTX_PP_PRIO == 3) __builtin_amdgcn_s_setprio(0); \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
         acc[(i0_) + i][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks], fb_[ks], acc[(i0_) + i][j_], 0, 0, 0); \
     if (ks == 0) { __builtin_amdgcn_sched_barrier(0); ISSUE_; HW_ __builtin_amdgcn_sched_barrier(0); HB_ }     \
   }                                                                                                    \
-  __builtin_amdgcn_s_setprio(0);
+  if (VTX_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (VTX_PP_PRIO == 3) __builtin_amdgcn_s_setprio(1);
 #define PP_BAR() __builtin_amdgcn_s_barrier()
 
   // One 64-deep K tile = four phases.  ISS_: what the request slots of the four MFMA sections issue; H1_ .. H4_:

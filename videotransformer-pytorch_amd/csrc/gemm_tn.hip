@@ -753,8 +753,18 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
 #define TP_MFMA1(i_, ks_, i0_, j_, fb_)                                                                  \
   acc[(i0_) + (i_)][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i_][ks_], fb_[ks_], acc[(i0_) + (i_)][j_], 0, 0, 0); \
   __builtin_amdgcn_sched_barrier(0);
+#ifndef VTX_TP_PRIO
+// Wave priority around the MMA sections.  Round 5, process-level A/B on the step (tools/micro/lib_ab.sh, two rounds, same box): with
+// `s_setprio 1` around every MMA section (rounds 2 - 4) the weight-gradient launches sum to 32.20 / 32.30 ms per step, without any
+// priority 32.01 / 32.01, static priority for the younger group 32.42 / 32.35, the LOAD sections at 1 32.23 / 32.18 -- here the load
+// section (16 transpose reads) is the longer side of the ping-pong and prioritising the partner's MFMAs only delays it.  (The NT kernel
+// is the other way round: no priority costs it 5 %, 478 vs 454 us per launch.)
+#define VTX_TP_PRIO 0   // 0 = none (default); 1 = s_setprio 1 around every MMA section; 2 = static (the younger group at 1); 3 = the load sections at 1
+#endif
+#define TP_PRIO_ON() do { if (VTX_TP_PRIO == 1) __builtin_amdgcn_s_setprio(1); else if (VTX_TP_PRIO == 3) __builtin_amdgcn_s_setprio(0); } while (0)
+#define TP_PRIO_OFF() do { if (VTX_TP_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (VTX_TP_PRIO == 3) __builtin_amdgcn_s_setprio(1); } while (0)
 #define TP_MMA(i0_, j_, fb_, H0_, H1_, H2_, H3_, H4_, H5_)                                               \
-  __builtin_amdgcn_s_setprio(1);                                                                         \
+  TP_PRIO_ON();                                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                     \
   TP_MFMA1(0, 0, i0_, j_, fb_) H0_; __builtin_amdgcn_sched_barrier(0);                                   \
   TP_MFMA1(1, 0, i0_, j_, fb_) H1_; __builtin_amdgcn_sched_barrier(0);                                   \
@@ -764,7 +774,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   TP_MFMA1(1, 2, i0_, j_, fb_) H5_; __builtin_amdgcn_sched_barrier(0);                                   \
   TP_MFMA1(0, 3, i0_, j_, fb_)                                                                           \
   TP_MFMA1(1, 3, i0_, j_, fb_)                                                                           \
-  __builtin_amdgcn_s_setprio(0);
+  TP_PRIO_OFF();
 #define TP_BAR() __builtin_amdgcn_s_barrier()
 
   bf16x8 fa[2][4], fb0[4], fb1[4];
@@ -778,6 +788,8 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   tn_wait_vmcnt<8>();                             // A0(0), B0(0), B1(0) landed; A1(0) A0(1) B0(1) B1(1) in flight
   TP_BAR();
   if (wr == 1) TP_BAR();
+  if (VTX_TP_PRIO == 2 && wr == 1) __builtin_amdgcn_s_setprio(1);
+  if (VTX_TP_PRIO == 3) __builtin_amdgcn_s_setprio(1);
   // The load sections must not outlast the partner group's 8-MFMA section (256 cycles), and a transpose read costs
   // ~14 cycles with four waves reading: 24 reads (A0 + B0) in P1 made every phase load-bound (tools/tn_timeline.py:
   // 4900 cycles per K tile).  The A fragments have to be read where they are (fa is busy in every MMA section), but a
@@ -868,6 +880,7 @@ __global__ __launch_bounds__(TP_THREADS, 2) void gemm_tn_bf16_pp_kernel(
   }
 #undef TP_KTILE
   if (wr == 0) TP_BAR();
+  if (VTX_TP_PRIO >= 2) __builtin_amdgcn_s_setprio(0);
 #undef TP_COLSUM
 #undef TP_READ_B_Q
 #undef TP_MFMA1
