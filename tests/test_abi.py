@@ -133,3 +133,16 @@ def test_continuous_flow_draw_register_is_private():
     if not os.path.exists(obj) or not os.path.exists(check_isa.OBJDUMP):
         pytest.skip('needs the compiled object of csrc/gemm_nt.hip and llvm-objdump')
     assert check_isa.check(obj) == []
+
+
+def test_one_wave_per_simd_weight_gradient_kernel_has_no_scratch_and_no_fragment_copies():
+    """gemm_tn=w4 (csrc/gemm_tn.hip): 505 registers per wave and fragment reads the compiler cannot see complete -- a spill or a
+    register copy between a transpose read and its counted wait breaks it silently or drains the LDS-DMA look-ahead (DESIGN 4.2;
+    tools/check_isa.py::check_tn_w4)."""
+    import sys
+    obj = os.path.join(ROOT, 'videotransformer-pytorch_amd', 'csrc', '_obj', 'gemm_tn.o')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_isa
+    if not os.path.exists(obj) or not os.path.exists(check_isa.OBJDUMP):
+        pytest.skip('needs the compiled object of csrc/gemm_tn.hip and llvm-objdump')
+    assert check_isa.check_tn_w4(obj) == []

@@ -86,9 +86,42 @@ def check(obj):
     return problems
 
 
+def check_tn_w4(obj):
+    """The one-wave-per-SIMD weight-gradient kernel (csrc/gemm_tn.hip, gemm_tn=w4) depends on three properties hipcc does not
+    guarantee: no scratch traffic (a spilled value is reloaded behind `s_waitcnt vmcnt(0)`, which drains the whole
+    LDS-DMA look-ahead), the transpose reads' 64-bit halves allocated as the aligned 128-bit tuples the MFMAs take (no v_mov
+    between a read and its use: a copy before the counted wait would move stale data), and the phase structure itself: 192
+    MFMAs (three copies of the K tile: the pair in the loop + the odd one), 32 + 3 x 64 transpose reads."""
+    problems, seen = [], 0
+    for name, body in kernels(disassemble(obj)):
+        if 'gemm_tn_bf16_w4_kernel' not in name:
+            continue
+        seen += 1
+        text = [l for l in body if l.strip()]
+        n_scratch = sum(1 for l in text if 'scratch_' in l)
+        n_mfma = sum(1 for l in text if 'v_mfma_f32_32x32x16_bf16' in l)
+        n_tr = sum(1 for l in text if 'ds_read_b64_tr_b16' in l)
+        idx = [i for i, l in enumerate(text) if 'v_mfma_f32_32x32x16_bf16' in l]
+        # inside the K-tile copies (consecutive MFMAs at most 200 lines apart; between the loop and the odd tile the allocator
+        # moves the 256 accumulators once per launch, which is harmless)
+        inside = [l for a, b in zip(idx, idx[1:]) if b - a <= 200 for l in text[a:b]]
+        n_mov64 = sum(1 for l in inside if 'v_mov_b64' in l)
+        n_acc_mov = sum(1 for l in inside if 'v_accvgpr' in l)
+        ok = n_scratch == 0 and n_mfma == 192 and n_tr == 224 and n_mov64 == 0 and n_acc_mov == 0
+        print(f'{name[:48]}: scratch {n_scratch}, mfma {n_mfma}, transpose reads {n_tr}, v_mov_b64 / accvgpr moves inside the K-tile copies '
+              f'{n_mov64} / {n_acc_mov}: {"ok" if ok else "VIOLATION"}')
+        if not ok:
+            problems.append(name)
+    if seen != 2:
+        problems.append(f'expected two gemm_tn_bf16_w4_kernel instantiations, found {seen}')
+    return problems
+
+
 if __name__ == '__main__':
     obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'videotransformer-pytorch_amd', 'csrc', '_obj', 'gemm_nt.o')
     bad = check(obj)
+    if len(sys.argv) <= 1:
+        bad += check_tn_w4(os.path.join(ROOT, 'videotransformer-pytorch_amd', 'csrc', '_obj', 'gemm_tn.o'))
     for b in bad:
         print('VIOLATION', b)
     sys.exit(1 if bad else 0)
