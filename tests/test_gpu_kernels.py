@@ -1170,7 +1170,7 @@ def test_hog_other_sizes_and_edges():
     from oracle import hog_oracle as H
     from vtx import ops
     rs = np.random.RandomState(3)
-    for shape in [(32, 48), (16, 16), (224, 224)]:
+    for shape in [(32, 48), (16, 16), (224, 224), (32, 272)]:      # W > 256: the one-channel-at-a-time kernel
         fr = rs.randint(0, 256, (2,) + shape + (3,)).astype(np.uint8)
         fr[1] = 0 if shape != (224, 224) else 255                    # constant frame -> all zeros
         got = ops.hog_fwd(torch.from_numpy(fr).to(DEV)).cpu().numpy()

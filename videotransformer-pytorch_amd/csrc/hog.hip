@@ -98,19 +98,26 @@ __device__ inline double hog_mag(int ar, int ac, unsigned word) {
 #endif
 }
 
-// frames [F,H,W,3] u8; grid = persistent workgroups over the F * (H/8) strips; block = 256 threads.
-__global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ frames, int F, int H, int W,
-                                                  const uint32_t* __restrict__ exc, double* __restrict__ out,
-                                                  int32_t* __restrict__ bins) {
+// frames [F,H,W,3] u8; grid = persistent workgroups over the F * (H/8) strips; block = 256 * CP threads.
+// CP = channels in parallel: 3 (W <= 256: threads 256 c .. 256 c + 255 work on channel c, every phase once per strip, 12 waves per
+// workgroup and two workgroups per CU) or 1 (wider frames: the three channels one after the other through one magnitude tile).
+template <int CP>
+__global__ __launch_bounds__(256 * CP, CP == 3 ? 6 : 1) void hog_kernel(const uint8_t* __restrict__ frames, int F, int H, int W,
+                                                       const uint32_t* __restrict__ exc, double* __restrict__ out,
+                                                       int32_t* __restrict__ bins) {
   extern __shared__ __attribute__((aligned(16))) char hsm[];
+  constexpr int T = 256 * CP;
   const int nc = W / 8, W3 = 3 * W;
   uint32_t* excs = reinterpret_cast<uint32_t*>(hsm);                                    // [4096]
   uint8_t* px = reinterpret_cast<uint8_t*>(hsm + HOG_EXC_WORDS * 4);                    // [10][3 W]  (30 W bytes, W % 16 == 0)
-  double* mag = reinterpret_cast<double*>(px + 10 * W3);                                // [nc][8 rows][8 columns]
-  uint32_t* msk = reinterpret_cast<uint32_t*>(mag + 8 * W);                             // [nc][9][2]
-  double* hist = reinterpret_cast<double*>(msk + nc * 18);                              // [nc][27]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < HOG_EXC_WORDS; i += 256) excs[i] = exc[i];
+  double* mag_all = reinterpret_cast<double*>(px + 10 * W3);                            // [CP][nc][8 rows][8 columns]
+  uint32_t* msk_all = reinterpret_cast<uint32_t*>(mag_all + CP * 8 * W);                // [CP][nc][9][2]
+  double* hist = reinterpret_cast<double*>(msk_all + CP * nc * 18);                     // [nc][27]
+  const int tid_all = threadIdx.x;
+  const int grp = CP == 1 ? 0 : tid_all >> 8, tid = CP == 1 ? tid_all : tid_all & 255;   // channel group of this thread
+  double* mag = mag_all + grp * 8 * W;
+  uint32_t* msk = msk_all + grp * nc * 18;
+  for (int i = tid_all; i < HOG_EXC_WORDS; i += T) excs[i] = exc[i];
   const int strips = H / 8;
   const long items = (long)F * strips;
   for (long item = blockIdx.x; item < items; item += gridDim.x) {
@@ -121,16 +128,18 @@ __global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ fr
     // rows y0-1 .. y0+8: one contiguous block of the frame, 16 bytes per load; rows outside the frame read as 0
     {
       const long first = (long)(y0 - 1) * W3, last = (long)H * W3;
-      for (int v = tid; v < (10 * W3) / 16; v += 256) {
+      for (int v = tid_all; v < (10 * W3) / 16; v += T) {
         const long g0 = first + (long)v * 16;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (g0 >= 0 && g0 < last) val = *reinterpret_cast<const uint4*>(img + g0);
         *reinterpret_cast<uint4*>(px + v * 16) = val;
       }
     }
-    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll 1
+    for (int chi = 0; chi < 3 / CP; ++chi) {
+      const int ch = CP == 1 ? chi : grp;
       for (int i = tid; i < nc * 18; i += 256) msk[i] = 0u;
-      __syncthreads();                               // pixels (ch 0) / masks cleared; phase B of the previous channel is done
+      __syncthreads();                               // pixels in place / masks cleared; phase B of the previous channel is done
       // (A) one pixel column per thread, eight rows
       for (int x = tid; x < W; x += 256) {
         const bool xin = x > 0 && x < W - 1;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ fr
       __syncthreads();
     }
     // (C) L2 norm per (cell, channel), in place
-    for (int i = tid; i < nc * 3; i += 256) {
+    for (int i = tid_all; i < nc * 3; i += T) {
       double* h = hist + (i / 3) * 27 + (i % 3) * 9;
       double s = ((h[0] * h[0] + h[1] * h[1]) + (h[2] * h[2] + h[3] * h[3])) +
                  ((h[4] * h[4] + h[5] * h[5]) + (h[6] * h[6] + h[7] * h[7]));
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void hog_kernel(const uint8_t* __restrict__ fr
     {
       const int ph = cr >> 1, dh = cr & 1;
       double* orow = out + (((long)f * (H / 16) + ph) * (W / 16)) * 108 + dh * 54;
-      for (int i = tid; i < (nc / 2) * 27; i += 256) {
+      for (int i = tid_all; i < (nc / 2) * 27; i += T) {
         const int pw = i / 27, j = i - pw * 27;
         *reinterpret_cast<double2*>(orow + (long)pw * 108 + 2 * j) = *reinterpret_cast<const double2*>(hist + pw * 54 + 2 * j);
       }
@@ -406,15 +415,23 @@ extern "C" int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const dou
   VTX_REQUIRE(frames && table && out, VTX_EINVAL, "hog_fwd: null pointer");
   VTX_REQUIRE(aligned16(frames) && aligned16(out), VTX_EALIGN, "hog_fwd: frames and out must be 16-byte aligned");
   const uint32_t* exc = reinterpret_cast<const uint32_t*>(table + 256 * 256);   // the correction words behind the 65 536 doubles
-  const size_t lds = (size_t)HOG_EXC_WORDS * 4 + (size_t)30 * W + (size_t)8 * W * 8 + (size_t)(W / 8) * 18 * 4 + (size_t)(W / 8) * 27 * 8;
+  // W <= 256: the three channels side by side (768 threads); wider frames: one channel at a time (256 threads, one magnitude tile)
+  const int cp = W <= 256 ? 3 : 1;
+  const size_t lds = (size_t)HOG_EXC_WORDS * 4 + (size_t)30 * W + (size_t)cp * 8 * W * 8 + (size_t)cp * (W / 8) * 18 * 4 + (size_t)(W / 8) * 27 * 8;
   static std::atomic<unsigned long long> attr_set{0};
-  if (first_launch_on_device(attr_set))
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  // persistent: as many workgroups as fit at once (LDS-limited), each walks strips with stride gridDim
+  if (first_launch_on_device(attr_set)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&hog_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&hog_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  // persistent: as many workgroups as fit at once (LDS- and wave-limited), each walks strips with stride gridDim
   const long items = (long)F * (H / 8);
-  long per_cu = (long)(160 * 1024) / (long)lds; if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
+  long per_cu = (long)(160 * 1024) / (long)lds; if (per_cu < 1) per_cu = 1;
+  const long wave_cap = 32 / (4 * cp); if (per_cu > wave_cap) per_cu = wave_cap;
   long grid = per_cu * device_cus(); if (grid > items) grid = items;
-  hipLaunchKernelGGL(hog_kernel, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), frames, F, H, W, exc, out, bins);
+  if (cp == 3)
+    hipLaunchKernelGGL(hog_kernel<3>, dim3((unsigned)grid), dim3(768), lds, as_stream(stream), frames, F, H, W, exc, out, bins);
+  else
+    hipLaunchKernelGGL(hog_kernel<1>, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), frames, F, H, W, exc, out, bins);
   return check_launch("hog_fwd");
 }
 
