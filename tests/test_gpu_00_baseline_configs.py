@@ -167,6 +167,12 @@ def test_maskfeat_head_vs_golden(prec, tol):
     check(f'maskfeat {prec} d decoder bias', m.decoder_pred.bias.grad.cpu(), g['d_decoder_b'], 2 * tol)
     check(f'maskfeat {prec} d decoder weight', m.decoder_pred.weight.grad[:8].cpu(), g['d_decoder_w_head'], 2 * tol)
     check(f'maskfeat {prec} d mask_token', m.mask_token.grad.cpu(), g['d_mask_token'], 4 * tol)
+    # visualize=True (reference :904-907): the reference resets center_index after every sample, so it returns the EMPTY frame
+    # selection rearranged to 'b t (h dh) (w dw) c o' and the all-False index -- same here, with the same prediction and loss
+    with torch.no_grad():
+        pv, lv, mp, ci = m(x, target.to(DEV), mask.to(DEV), markers, visualize=True)
+    assert tuple(mp.shape) == (2, 0, 28, 28, 3, 9) and ci.dtype == torch.bool and tuple(ci.shape) == (16,) and not ci.any()
+    assert torch.equal(pv, pred.detach()) and abs(lv.item() - loss.item()) <= 1e-12 * abs(loss.item())     # (the loss sums with float64 atomics)
 
 
 @pytest.mark.parametrize('prec,tol,gtol', PRECS)

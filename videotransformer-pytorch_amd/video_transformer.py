@@ -450,7 +450,13 @@ class MaskFeat(nn.Module):
         x = F_.CastFn.apply(pred, torch.float32).reshape(B, tq, g, g, ts, cf).permute(0, 1, 4, 2, 3, 5)
         x = x.reshape(B, self.num_frames, g, g, cf)
         if visualize:
-            raise NotImplementedError('vtx: visualize=True (reference :904-907) is not implemented')
+            # reference :904-907, kept literal: `center_index` is reset after every sample of the loop above it (:892), so what
+            # the reference returns is the EMPTY selection x[:, no frame] rearranged to 'b t (h dh) (w dw) c o' and the all-False
+            # index ("need to update" in the reference); consumers get the same shapes and values here
+            center_index = torch.zeros(self.num_frames, dtype=torch.bool, device=x.device)
+            mp = x[:, center_index]
+            mp = mp.reshape(B, mp.shape[1], g, g, 2, 2, 3, 9).permute(0, 1, 2, 4, 3, 5, 6, 7).reshape(B, mp.shape[1], 2 * g, 2 * g, 3, 9)
+            return x, loss, mp, center_index
         return x, loss
 
     def forward(self, x, target_x, mask, cube_marker, visualize=False):
