@@ -306,6 +306,7 @@ __global__ void patch_rows_kernel(int B, int Tn, int C, int H, int W, int ps, in
   const int gh = H / ps, gw = W / ps, P = gh * gw, Tq = Tn / ts;
   const long runs_per_row = (long)C * ts * ps;                 // (c, kt, kh)
   const long total = (long)B * Tq * P * runs_per_row;
+  const bool vec8 = (ps & 7) == 0 && (ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     // idx -> (b, tq, ph, c, kt, kh, pw): pw fastest so that neighbouring threads read neighbouring pixels
     long r = idx;
@@ -320,9 +321,19 @@ __global__ void patch_rows_kernel(int B, int Tn, int C, int H, int W, int ps, in
     const int p = ph * gw + pw;
     const long row = frame_major ? ((long)b * Tq + tq) * P + p : ((long)b * P + p) * Tq + tq;
     T* dst = rows + row * ldr + ((long)(c * ts + kt) * ps + kh) * ps;
-    for (int kw = 0; kw < ps; kw += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(src + kw);
-      ET<T>::st(dst + kw, v.x); ET<T>::st(dst + kw + 1, v.y); ET<T>::st(dst + kw + 2, v.z); ET<T>::st(dst + kw + 3, v.w);
+    if (vec8) {
+      // eight pixels per store: one 16-byte (bf16) or two 16-byte (fp32) stores instead of eight 2- / 4-byte ones (round 5:
+      // the run's 64 B were read with four loads and written with sixteen 2-byte stores, 2.3 TB/s)
+      for (int kw = 0; kw < ps; kw += 8) {
+        float v[8];
+        load8(src + kw, v);
+        store8(dst + kw, v);
+      }
+    } else {
+      for (int kw = 0; kw < ps; kw += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + kw);
+        ET<T>::st(dst + kw, v.x); ET<T>::st(dst + kw + 1, v.y); ET<T>::st(dst + kw + 2, v.z); ET<T>::st(dst + kw + 3, v.w);
+      }
     }
   }
 }
