@@ -157,3 +157,26 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_ca
             assert mo <= 1.25 * mt, f'{prefix}: median gradient error {mo:.3e} > 1.25 x the reference autocast median {mt:.3e}'
     report(f'ok   {prefix}: {n} parameter gradients, worst max-rel={worst_max:.3e} l2-rel={worst_l2:.3e} (tol {tol:g}){extra}')
     return worst_max
+
+
+def integration_stub_source():
+    """The fenced Python block of INTEGRATION.md section 2 (the ctypes stub a maintainer of the reference would add)."""
+    import re
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sec = text.split('## 2. Binding the C ABI directly', 1)[1]
+    return re.search(r'```python\n(.*?)```', sec, flags=re.S).group(1)
+
+
+def exec_integration_stub():
+    """Execute the documented stub against the in-tree library (its CDLL path comes from VTX_LIB) and return its namespace."""
+    old = os.environ.get('VTX_LIB')
+    os.environ['VTX_LIB'] = os.path.join(ROOT, 'videotransformer-pytorch_amd', 'libvtx.so')
+    try:
+        ns = {}
+        exec(compile(integration_stub_source(), 'INTEGRATION.md#stub', 'exec'), ns)
+    finally:
+        if old is None:
+            del os.environ['VTX_LIB']
+        else:
+            os.environ['VTX_LIB'] = old
+    return ns

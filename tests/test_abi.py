@@ -85,6 +85,39 @@ def test_struct_layouts_match_ctypes(tmp_path):
             assert got[(cname, fname)] == getattr(cls, fname).offset, f'{cname}.{fname}: offset differs'
 
 
+def test_integration_stub_matches_the_header(tmp_path):
+    """INTEGRATION.md section 2 is the binding a maintainer copies: execute the documented block and hold its RowMap and
+    argument list against include/vtx.h as gcc lays it out (round 3 added vtx_rowmap.tab; the stub kept three fields for
+    two rounds and would have passed stack garbage as the table pointer)."""
+    import subprocess
+    from helpers import exec_integration_stub
+    _lib_path()
+    ns = exec_integration_stub()
+    RowMap = ns['RowMap']
+    probe = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "vtx.h")}"', 'int main(void) {',
+             '  printf("size %zu\\n", sizeof(vtx_rowmap));']
+    for fname, _ in RowMap._fields_:
+        probe.append(f'  printf("{fname} %zu\\n", offsetof(vtx_rowmap, {fname}));')
+    probe += ['  return 0;', '}']
+    src = tmp_path / 'rowmap.c'
+    src.write_text('\n'.join(probe))
+    exe = tmp_path / 'rowmap'
+    subprocess.run(['gcc', '-std=c99', '-o', str(exe), str(src)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got['size']) == ctypes.sizeof(RowMap) == 24
+    for fname, _ in RowMap._fields_:
+        assert int(got[fname]) == getattr(RowMap, fname).offset, fname
+    from vtx import _lib
+    assert [f for f, _ in RowMap._fields_] == [f for f, _ in _lib.RowMap._fields_]
+    # the documented argument list = the repository's own binding of the same entry point (by ctypes size and kind)
+    doc = ns['_vtx'].vtx_layernorm_fwd.argtypes
+    own = _lib.SIGNATURES['vtx_layernorm_fwd'][1]
+    assert len(doc) == len(own) == 15
+    for a, b in zip(doc, own):
+        assert ctypes.sizeof(a) == ctypes.sizeof(b), (a, b)
+        assert issubclass(a, ctypes.Structure) == issubclass(b, ctypes.Structure), (a, b)
+
+
 def test_bench_traffic_helper_reads_committed_pmc_passes():
     """bench.py derives roofline.traffic from the committed rocprofv3 PMC dumps of the default command
     (profiles/round2_pmc_{FETCH,WRITE}_SIZE_b<batch>.txt); any other configuration has no counters."""

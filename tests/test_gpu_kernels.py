@@ -110,6 +110,22 @@ def test_layernorm_fwd_bwd(dtype, D):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_integration_stub_layer_norm(dtype):
+    """The ctypes stub INTEGRATION.md section 2 documents, extracted from the document and executed as written (its own
+    CDLL handle, its own RowMap), against torch.nn.functional.layer_norm in float64 -- reference transformer.py:519."""
+    from helpers import exec_integration_stub
+    ns = exec_integration_stub()
+    rows, D = 1569, 768
+    x = rnd(rows, D, seed=11) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * rnd(D, seed=12), 0.1 * rnd(D, seed=13)
+    y = ns['layer_norm_hip'](dev(x, dtype), dev(gamma), dev(beta), 1e-5)
+    torch.cuda.synchronize()
+    assert y.dtype == dtype and y.shape == (rows, D)
+    ref = torch.nn.functional.layer_norm(q(x, dtype), (D,), gamma.double(), beta.double(), 1e-5)
+    check(f'INTEGRATION.md stub layer_norm_hip {dtype}', y.float().cpu(), ref, TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('D', [128, 200, 768, 1024])
 def test_layernorm_fwd_rows_per_trip(dtype, D, vtx_opts):
     """The forward kernel with 2 / 3 / 4 rows per trip (all rows requested before the first is reduced; the default is 3)
