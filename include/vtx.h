@@ -296,7 +296,10 @@ int vtx_embed_table(int dtype, int P, int T, int D, const float* bias, const flo
  * bins (optional): [F,3,H,W] int32 orientation-bin ids. */
 size_t vtx_hog_table_bytes(void);
 int vtx_hog_build_table(double* host_table);
-int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table,
+/* table_bytes: size of the uploaded blob (vtx_version() >= 210).  The kernel reads the correction words BEHIND the 512 KB of
+ * magnitudes, so a blob of the pre-210 layout (magnitudes only) is rejected with VTX_EINVAL instead of being read 16 KB beyond
+ * its end. */
+int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table, size_t table_bytes,
                 double* out, int32_t* bins, void* stream);
 
 /* ------------------------------------------------------------ MaskFeat head

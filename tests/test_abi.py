@@ -50,7 +50,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     d.dtype, d.M, d.N, d.K = 1, 16, 12, 64                      # N not a multiple of 8
     assert lib.vtx_gemm_nt(ctypes.byref(d), None) == -1
     assert b'multiples of 8' in lib.vtx_last_error_string()
-    assert lib.vtx_hog_fwd(None, 1, 224, 224, None, None, None, None) == -1
+    assert lib.vtx_hog_fwd(None, 1, 224, 224, None, 0, None, None, None) == -1
     a = _lib.AttnDesc()
     a.S, a.L, a.H, a.hd = 1, 8, 2, 48                            # unsupported head dim
     assert lib.vtx_attn_fwd(ctypes.byref(a), None) == -1

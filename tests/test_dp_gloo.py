@@ -101,6 +101,67 @@ def test_unfired_parameters_are_agreed_across_ranks():
     assert ret[0][2] == ret[1][2]
 
 
+def _worker_static_unused(rank, world, port, ret):
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vtx import dp
+    torch.manual_seed(5)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())      # c: registered last = buckets 0 and 1
+    buckets = dp.GradBuckets(params, bucket_bytes=64, static_unused=True)
+    nb = len(buckets.buckets)
+    x = torch.ones(2, 4) * (rank + 1)
+    out = {}
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        for step in range(3):
+            buckets.zero()
+            (a(x) + b(x)).sum().backward()                   # nobody ever runs c
+            out[f'next{step}'] = buckets._next              # buckets that went out DURING backward
+            buckets.finish()
+            buckets.unfired()
+    out['warnings'] = err.getvalue().count('finish() had to issue')
+    out['nb'] = nb
+    out['grad'] = a.weight.grad.clone()
+    # the graph changes after all: c gets a gradient although every rank had agreed it is unused.  Its buckets (0 and 1, all of
+    # their parameters known unused) go out as soon as the first gradient of the step arrives, so c's gradient comes too late
+    buckets.zero()
+    try:
+        (c(a(x)) + b(x)).sum().backward()                   # b's gradients arrive first (created last), then c's
+        out['late'] = 'no error'
+    except RuntimeError as e:
+        out['late'] = 'raised' if 'static_unused' in str(e) else repr(e)
+    ret[rank] = out
+    if out['late'] != 'raised':
+        buckets.finish()
+    dist.destroy_process_group()
+
+
+def test_static_unused_parameters_release_their_buckets():
+    """buckets go out strictly in order, so ONE parameter without a gradient (here: a whole unused layer registered
+    last = buckets 0 and 1) holds every bucket back until finish() -- no overlap with backward, reported once on stderr.  With
+    static_unused=True the set unfired() agrees on across ranks no longer counts from the next step on: every bucket goes out
+    during backward again.  A parameter of that set that does get a gradient later raises instead of being lost."""
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_static_unused, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        o = ret[r]
+        assert o['next0'] == 0, 'step 0: the unused layer holds every bucket back'
+        assert o['warnings'] == 1, 'the held buckets are reported exactly once'
+        assert o['next1'] == o['nb'] and o['next2'] == o['nb'], (o['next1'], o['next2'], o['nb'])
+        assert o['late'] == 'raised', o['late']
+    # mean over ranks of d/dW sum(a(x)) = mean of x summed over the batch: (2 * 1 + 2 * 2) / 2 = 3 per weight column
+    assert torch.allclose(ret[0]['grad'], torch.full((4, 4), 3.0)) and torch.equal(ret[0]['grad'], ret[1]['grad'])
+
+
 def test_shard_clips_partition():
     sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
     from vtx import dp

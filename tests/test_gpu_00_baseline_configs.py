@@ -117,6 +117,28 @@ def test_timesformer_l_t96_train_vs_golden(prec, tol, gtol):
 
 
 @pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
+def test_timesformer_l_t96_full_depth_eval_vs_golden(prec, tol):
+    """BASELINE.json configs[4] at FULL depth: TimeSformer-L (D 1024, 16 heads, 24 layers) on one 96x3x224x224
+    clip, eval-mode forward against the reference's own fp32 run (tests/golden/make_golden_r6.py: 18 817 tokens through 24 layers,
+    where accumulated rounding of the bf16 residual stream would show).  The bf16 line carries the reference's own
+    torch.autocast(bfloat16) deviation on the same forward; the bar is the FIXED one."""
+    import vtx
+    import video_transformer as V
+    vtx.set_precision(prec)
+    g = gold('tsf_l_t96_d24_eval.npz')
+    m, _ = _build(V.TimeSformer, 0, num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=24)
+    m.eval()
+    with torch.no_grad():
+        y = m(synth.synth_clip(1, 96, seed=5).to(DEV))
+    e = check(f'TimeSformer-L T=96 depth 24 eval {prec} out', y.cpu(), g['out'], tol)
+    if prec == 'bf16':
+        ref_dev = relerr(g['out_autocast'], g['out'])
+        report(f'     reference autocast output deviation {ref_dev:.3e}, this path {e:.3e}')
+    del m
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', TOL_F32), ('bf16', TOL_BF16)])
 def test_vivit_b_forward(prec, tol):
     """BASELINE.json configs[2] shape: ViViT-B fact_encoder, Conv3d tubelets, 16 frames."""
     import vtx

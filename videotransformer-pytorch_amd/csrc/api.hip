@@ -114,7 +114,7 @@ int hog_selftest(int* bad_mag, int* bad_bin);     // hog.hip
 
 using namespace vtx;
 
-extern "C" int vtx_version(void) { return 200; }  // 0.2.0
+extern "C" int vtx_version(void) { return 210; }  // 0.2.1: vtx_hog_fwd takes the size of the table blob
 
 extern "C" int vtx_set_option(const char* name, const char* value) {
   const int rc = set_option(options(), name, value);

@@ -386,33 +386,47 @@ namespace vtx {
 // part of vtx_selftest (api.hip): 0 = the device reproduces the host's hypot for all 65 536 gradient pairs and the integer
 // bin rule equals the float64 sign tests for all 511 x 511 pairs
 int hog_selftest(int* bad_mag, int* bad_bin) {
+  // (defined counts on every path -- 0 mismatches can only come from a completed comparison --, every device buffer
+  // freed on every path, every runtime call checked)
+  *bad_mag = 65536; *bad_bin = 511 * 511;
   std::vector<double> tab(vtx_hog_table_bytes() / 8);
   if (vtx_hog_build_table(tab.data()) != VTX_OK) return -1;
   uint32_t* d_exc = nullptr; double* d_mag = nullptr; int *d_bi = nullptr, *d_bf = nullptr;
   const int NB = 511 * 511;
-  if (hipMalloc(&d_exc, HOG_EXC_WORDS * 4) != hipSuccess || hipMalloc(&d_mag, 65536 * 8) != hipSuccess ||
-      hipMalloc(&d_bi, NB * 4) != hipSuccess || hipMalloc(&d_bf, NB * 4) != hipSuccess) return -1;
-  hipMemcpy(d_exc, tab.data() + 65536, HOG_EXC_WORDS * 4, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(hog_probe_kernel, dim3((NB + 255) / 256), dim3(256), 0, 0, d_exc, d_mag, d_bi, d_bf);
   std::vector<double> mags(65536);
   std::vector<int> bi(NB), bf(NB);
-  hipMemcpy(mags.data(), d_mag, 65536 * 8, hipMemcpyDeviceToHost);
-  hipMemcpy(bi.data(), d_bi, NB * 4, hipMemcpyDeviceToHost);
-  hipMemcpy(bf.data(), d_bf, NB * 4, hipMemcpyDeviceToHost);
+  bool ok = hipMalloc(&d_exc, HOG_EXC_WORDS * 4) == hipSuccess && hipMalloc(&d_mag, 65536 * 8) == hipSuccess &&
+            hipMalloc(&d_bi, NB * 4) == hipSuccess && hipMalloc(&d_bf, NB * 4) == hipSuccess;
+  ok = ok && hipMemcpy(d_exc, tab.data() + 65536, HOG_EXC_WORDS * 4, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(hog_probe_kernel, dim3((NB + 255) / 256), dim3(256), 0, 0, d_exc, d_mag, d_bi, d_bf);
+    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  }
+  ok = ok && hipMemcpy(mags.data(), d_mag, 65536 * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(bi.data(), d_bi, NB * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(bf.data(), d_bf, NB * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  if (d_exc) (void)hipFree(d_exc);
+  if (d_mag) (void)hipFree(d_mag);
+  if (d_bi) (void)hipFree(d_bi);
+  if (d_bf) (void)hipFree(d_bf);
+  if (!ok) return -1;
   *bad_mag = 0; *bad_bin = 0;
   for (int i = 0; i < 65536; ++i) *bad_mag += memcmp(&mags[i], &tab[i], 8) != 0;
   for (int i = 0; i < NB; ++i) *bad_bin += bi[i] != bf[i];
-  hipFree(d_exc); hipFree(d_mag); hipFree(d_bi); hipFree(d_bf);
   return 0;
 }
 }  // namespace vtx
 
-extern "C" int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table, double* out, int32_t* bins,
-                           void* stream) {
+extern "C" int vtx_hog_fwd(const uint8_t* frames, int F, int H, int W, const double* table, size_t table_bytes, double* out,
+                           int32_t* bins, void* stream) {
   VTX_REQUIRE(F >= 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && W <= 1024, VTX_EINVAL,
               "hog_fwd: H=%d, W=%d must be multiples of 16 (W <= 1024)", H, W);
   if (F == 0) return VTX_OK;                       // empty batch: nothing to do (pointers may be null)
   VTX_REQUIRE(frames && table && out, VTX_EINVAL, "hog_fwd: null pointer");
+  // the blob is 512 KB of magnitudes + the 16 KB of correction words the kernel reads: a caller that still uploads the
+  // magnitude table of library version 200 and earlier (512 KB) would have the kernel read 16 KB beyond it
+  VTX_REQUIRE(table_bytes >= vtx_hog_table_bytes(), VTX_EINVAL, "hog_fwd: the table blob holds %zu bytes, vtx_hog_table_bytes() = %zu "
+              "(magnitudes + correction words: build it with vtx_hog_build_table)", table_bytes, vtx_hog_table_bytes());
   VTX_REQUIRE(aligned16(frames) && aligned16(out), VTX_EALIGN, "hog_fwd: frames and out must be 16-byte aligned");
   const uint32_t* exc = reinterpret_cast<const uint32_t*>(table + 256 * 256);   // the correction words behind the 65 536 doubles
   // W <= 256: the three channels side by side (768 threads); wider frames: one channel at a time (256 threads, one magnitude tile)

@@ -11,17 +11,30 @@
 // 16-byte vectors), and optionally the vector product that shares the A tiles already on chip:
 //     y[i] (+)= alpha_y * sum_k A(i,k) x[k] + beta_z * z[i].
 //
-// 64 x 64 output tile per 512-thread workgroup: 8 waves = 4 quadrants of 32 x 32 (v_mfma_f32_32x32x2_f32, an fp32 fma
-// chain) x 2 halves of every 64-deep K tile, folded through LDS in a fixed order (deterministic).  768^3: 144
-// workgroups, 192 matrix instructions of 64 cycles per wave = 12.3k cycles; operands are L2-resident (2.4 MB each).
-// LDS tiles are k-major [64][65]: fragment reads are 32 consecutive words per lane group, and both store patterns
-// (vector along k / vector along i) are bank-conflict free with the odd row stride.
+// 32 x 32 output tile per 256-thread workgroup (round 6; 64 x 64 tiles staged through LDS before: 144 workgroups on 256 CUs, twelve
+// barrier-separated K tiles, 33 - 38 us per 768^3 product against a matrix-pipe floor of 10): 4 waves = 4 quarters of K, every wave
+// runs the whole 32 x 32 tile over its quarter (blocks h, h + 4, ... of 8 k) with v_mfma_f32_32x32x2_f32 (an fp32 fma chain) and takes its operands STRAIGHT from
+// L2 into the instruction's registers -- no LDS staging, no barrier inside the K loop; the quarters are folded through LDS in a
+// fixed order (deterministic).  Operand layout of the instruction: lane l holds A(i = l % 32, k = l / 32) and B(k = l / 32,
+// j = l % 32).  A block of 8 consecutive k is four instructions; instruction s of a block takes k0 + s from lanes 0 .. 31 and
+// k0 + 4 + s from lanes 32 .. 63, so that a lane's four values are ONE 16-byte load when the operand is contiguous along k (four
+// 4-byte loads of 128 contiguous bytes per half wave otherwise).  768^3: 576 workgroups (2 - 3 per CU), 96 matrix instructions of
+// 64 cycles per wave; operands are L2-resident (2.4 MB each, 113 MB of L2 reads per product).  WP_D blocks of look-ahead per wave.
 // Algorithmic work per launch: 2*N1*N2*K flop, (N1*K + K*N2 + N1*N2) * 4 bytes.
 #include "common.h"
 
 namespace vtx {
 
-constexpr int WP_T = 64, WP_BK = 64, WP_LD = 65, WP_THREADS = 512, WP_V = WP_T * WP_BK / 4 / WP_THREADS;   // float4 per thread, operand and K tile
+#ifndef VTX_WP_PAD_KB
+#define VTX_WP_PAD_KB 0
+#endif
+#ifndef VTX_WP_NACC
+#define VTX_WP_NACC 2
+#endif
+#ifndef VTX_WP_D
+#define VTX_WP_D 4
+#endif
+constexpr int WP_T = 32, WP_THREADS = 256, WP_D = VTX_WP_D;
 
 struct WprodParams {
   int N1, N2, K;
@@ -31,127 +44,140 @@ struct WprodParams {
   float* C; long ldc; int accumulate;
   const float* u; const float* v;
   const float* x; float* y; float alpha_y; const float* z; float beta_z; int y_accumulate;
+  long long* trace;                                    // VTX_WP_TRACE builds (tools/micro/wprod_timeline.py): 8 stamps per wave
 };
 
-template <bool A_KCONT, bool B_KCONT>
+#ifdef VTX_WP_TRACE
+#define WP_STAMP(e_) if (p.trace != nullptr && lane == 0) { \
+    long long* sl__ = p.trace + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + h) * 8; \
+    sl__[e_] = (long long)__builtin_amdgcn_s_memrealtime(); if ((e_) == 0 || (e_) == 3) sl__[(e_) == 0 ? 6 : 7] = (long long)__builtin_amdgcn_s_memtime(); }
+#else
+#define WP_STAMP(e_)
+#endif
+
+// FULL: N1, N2 multiples of 32 and K of 32 * WP_D (no lane ever holds a row / column / k beyond the extents: no selects in the K loop);
+// WITH_X: the vector product rides along (x loads and four multiply-adds per block)
+template <bool A_KCONT, bool B_KCONT, bool FULL, bool WITH_X>
 __global__ __launch_bounds__(WP_THREADS) void wprod_kernel(WprodParams p) {
-  __shared__ __attribute__((aligned(16))) float As[2][WP_BK][WP_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][WP_BK][WP_LD];
-  __shared__ float xs[2][WP_BK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = wave & 3, qi = q >> 1, qj = q & 1, h = wave >> 2;
+  __shared__ float red[3][16][64];                     // accumulators of K quarters 1 .. 3
+  __shared__ float yred[4][32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);          // K quarter
+  const int li = lane & 31, kh = lane >> 5;
+  WP_STAMP(0)
   const int i0 = blockIdx.y * WP_T, j0 = blockIdx.x * WP_T;
-  const bool with_y = p.y != nullptr && blockIdx.x == 0;
+  const int row = i0 + li, col = j0 + li;              // the lane's row of A / column of B
+  const bool row_ok = row < p.N1, col_ok = col < p.N2;
+  const bool with_y = WITH_X && blockIdx.x == 0;
+  const int nb = (p.K + 7) >> 3;                       // blocks of 8 k (K is a multiple of 4: the last block may hold 4)
+  // blocks per wave, a multiple of the look-ahead: the K loop below is straight-line code per trip (a wave-uniform `if` around a
+  // slot makes hipcc wait for every load in flight at the top of each trip); blocks beyond K are all zeros
+  const int per = (((nb + 3) >> 2) + WP_D - 1) / WP_D * WP_D;
+  // wave h takes blocks h, h + 4, h + 8, ...: the four waves of a workgroup then walk the SAME 128-byte lines of a k-contiguous
+  // operand at the same time (a line = four blocks of a row), so a line comes out of L2 once per workgroup and the workgroup's
+  // window is 64 lines.  (With a contiguous quarter of K per wave every wave had its own 64-line window -- 9 .. 12 of them per
+  // CU against a 32-KB vector L1 -- and every line was fetched four times: TCP_TCC_READ_REQ 4x the operand bytes.)
+  const int b_lo = 0, b_hi = per;
+  const float* const arow = p.A + (A_KCONT ? (long)(row_ok ? row : 0) * p.a_rs : (long)(row_ok ? row : 0));
+  const float* const bcol = p.B + (B_KCONT ? (long)(col_ok ? col : 0) * p.b_cs : (long)(col_ok ? col : 0));
 
-  // loader coordinates of float4 v of this thread (index tid + v * 512 of the tile's 1024): k-contiguous operands are cut into
-  // float4 along k (16 per row of the other axis), the others along i / j (16 per k)
-  auto a_k = [&](int v) { const int id = tid + v * WP_THREADS; return A_KCONT ? (id & 15) * 4 : id >> 4; };
-  auto a_i = [&](int v) { const int id = tid + v * WP_THREADS; return A_KCONT ? id >> 4 : (id & 15) * 4; };
-  auto b_k = [&](int v) { const int id = tid + v * WP_THREADS; return B_KCONT ? (id & 15) * 4 : id >> 4; };
-  auto b_j = [&](int v) { const int id = tid + v * WP_THREADS; return B_KCONT ? id >> 4 : (id & 15) * 4; };
-  // Operand tiles are L2-resident but an L2 round trip (~1 us under load) is several times the matrix instructions of a
-  // K tile: three K tiles of register prefetch keep the loop on the matrix pipe instead of on that latency
-  // (one tile of look-ahead measured 45 us per 768^3 product, latency-bound).  64-deep K tiles (round 4; 32 before): half as many
-  // barrier-separated iterations, each of which is bound by its latency chain, not by its 16 matrix instructions.
-  constexpr int PF = 3;
-  float4 ra[PF][WP_V], rb[PF][WP_V];
-  float rx[PF] = {0.f, 0.f, 0.f};
-  auto gload = [&](int k0, float4 (&va)[WP_V], float4 (&vb)[WP_V], float& vx) {
+  // x rides along in EVERY workgroup of a launch that has one (one broadcast 16-byte load per block): a load under a run-time
+  // branch makes hipcc wait for ALL loads in flight at the join, which would empty the look-ahead
+  const float* const xbase = WITH_X ? p.x : p.A;
+  float a[WP_D][4], b[WP_D][4], xv[WP_D][4];
+  auto load = [&](int blk, float (&va)[4], float (&vb)[4], float (&vx)[4]) {      // the lane's four k of block blk: kk .. kk + 3
+    const int kk = (blk * 4 + h) * 8 + kh * 4;
+    const int ks = kk < p.K ? kk : 0;                  // blocks / vectors beyond K read the first one (a whole vector is inside or
+                                                       // outside K); nothing is zeroed here -- a select on a value that has just been
+                                                       // requested is a wait for it
+    if (A_KCONT) {
+      const float4 t = *reinterpret_cast<const float4*>(arow + ks);
+      va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w;
+    } else {
 #pragma unroll
-    for (int v = 0; v < WP_V; ++v) {
-      {
-        const int i = i0 + a_i(v), k = k0 + a_k(v);
-        const bool ok = i < p.N1 && k < p.K;         // extents are multiples of 4: a vector is inside or outside as a whole
-        const float* src = p.A + (ok ? (long)i * p.a_rs + (long)k * p.a_ks : 0L);
-        va[v] = *reinterpret_cast<const float4*>(src);
-        if (!ok) va[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      {
-        const int j = j0 + b_j(v), k = k0 + b_k(v);
-        const bool ok = j < p.N2 && k < p.K;
-        const float* src = p.B + (ok ? (long)k * p.b_ks + (long)j * p.b_cs : 0L);
-        vb[v] = *reinterpret_cast<const float4*>(src);
-        if (!ok) vb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int s = 0; s < 4; ++s) va[s] = arow[(long)(ks + s) * p.a_ks];
     }
-    if (with_y && tid < WP_BK) vx = (k0 + tid) < p.K ? p.x[k0 + tid] : 0.f;
-  };
-  auto lstore = [&](int buf, const float4 (&va)[WP_V], const float4 (&vb)[WP_V], float vx) {
+    if (B_KCONT) {
+      const float4 t = *reinterpret_cast<const float4*>(bcol + ks);
+      vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
+    } else {
 #pragma unroll
-    for (int v = 0; v < WP_V; ++v) {
-      const int ak = a_k(v), ai = a_i(v), bk = b_k(v), bj = b_j(v);
-      if (A_KCONT) { As[buf][ak][ai] = va[v].x; As[buf][ak + 1][ai] = va[v].y; As[buf][ak + 2][ai] = va[v].z; As[buf][ak + 3][ai] = va[v].w; }
-      else { As[buf][ak][ai] = va[v].x; As[buf][ak][ai + 1] = va[v].y; As[buf][ak][ai + 2] = va[v].z; As[buf][ak][ai + 3] = va[v].w; }
-      if (B_KCONT) { Bs[buf][bk][bj] = vb[v].x; Bs[buf][bk + 1][bj] = vb[v].y; Bs[buf][bk + 2][bj] = vb[v].z; Bs[buf][bk + 3][bj] = vb[v].w; }
-      else { Bs[buf][bk][bj] = vb[v].x; Bs[buf][bk][bj + 1] = vb[v].y; Bs[buf][bk][bj + 2] = vb[v].z; Bs[buf][bk][bj + 3] = vb[v].w; }
+      for (int s = 0; s < 4; ++s) vb[s] = bcol[(long)(ks + s) * p.b_ks];
     }
-    if (with_y && tid < WP_BK) xs[buf][tid] = vx;
+    if constexpr (WITH_X) {
+      const float4 t = *reinterpret_cast<const float4*>(xbase + ks);
+      vx[0] = t.x; vx[1] = t.y; vx[2] = t.z; vx[3] = t.w;
+    }
   };
 
-  f32x16 acc;
+  // VTX_WP_NACC accumulators take the matrix instructions of a block in turn (2: instructions 0, 2 and 1, 3 -- no instruction
+  // waits for the one right in front of it; the two are added at the end)
+  f32x16 accs[VTX_WP_NACC];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c = 0; c < VTX_WP_NACC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accs[c][r] = 0.f;
   float yacc = 0.f;
-  const int fa = qi * 32 + (lane & 31), fb = qj * 32 + (lane & 31), fk = h * (WP_BK / 2) + (lane >> 5);
-  const int nk = (p.K + WP_BK - 1) / WP_BK;
-  // register slot of K tile t = t % PF; LDS buffer = t & 1.  Tile t is consumed while tiles t+1 .. t+PF are in flight.
 #pragma unroll
-  for (int s = 0; s < PF; ++s)
-    if (s < nk) gload(s * WP_BK, ra[s], rb[s], rx[s]);
-  lstore(0, ra[0], rb[0], rx[0]);
-  if (PF < nk) gload(PF * WP_BK, ra[0], rb[0], rx[0]);
-  __syncthreads();
-  auto ktile = [&](int kt, float4 (&va)[WP_V], float4 (&vb)[WP_V], float& vx) {   // va/vb/vx: the slot that holds tile kt + 1
-    const int buf = kt & 1;
+  for (int d = 0; d < WP_D; ++d) { load(b_lo + d, a[d], b[d], xv[d]); __builtin_amdgcn_sched_barrier(0); }
+  WP_STAMP(1)
+  bool first_trip = true;
+  for (int blk = b_lo; blk < b_hi; blk += WP_D) {
 #pragma unroll
-    for (int s = 0; s < WP_BK / 4; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][fk + 2 * s][fa], Bs[buf][fk + 2 * s][fb], acc, 0, 0, 0);
-    if (with_y && wave == 0) {                        // rows i0 .. i0+63 of A times x, k ascending: lane = row
+    for (int d = 0; d < WP_D; ++d) {
+      const bool kok = FULL || ((blk + d) * 4 + h) * 8 + kh * 4 < p.K;   // rows / columns / k beyond the extents contribute zeros
+      const bool aok = FULL || (kok && row_ok), bok = FULL || (kok && col_ok);
 #pragma unroll
-      for (int k = 0; k < WP_BK; ++k) yacc = fmaf(As[buf][k][lane], xs[buf][k], yacc);
+      for (int s = 0; s < 4; ++s) {
+        const float av = aok ? a[d][s] : 0.f, bv = bok ? b[d][s] : 0.f;
+        accs[s % VTX_WP_NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accs[s % VTX_WP_NACC], 0, 0, 0);
+        if constexpr (WITH_X) yacc = fmaf(av, xv[d][s], yacc);
+      }
+      load(blk + d + WP_D, a[d], b[d], xv[d]);         // the slot is free again (beyond the wave's range: loaded, never used)
+      __builtin_amdgcn_sched_barrier(0);               // keep the request order: hipcc otherwise sinks the loads to their uses (no look-ahead left)
     }
-    if (kt + 1 < nk) {
-      lstore(buf ^ 1, va, vb, vx);
-      if (kt + 1 + PF < nk) gload((kt + 1 + PF) * WP_BK, va, vb, vx);   // the slot is free again: tile kt + 1 + PF
-    }
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nk; kt += PF) {
-    ktile(kt, ra[1], rb[1], rx[1]);
-    if (kt + 1 < nk) ktile(kt + 1, ra[2], rb[2], rx[2]);
-    if (kt + 2 < nk) ktile(kt + 2, ra[0], rb[0], rx[0]);
+#ifdef VTX_WP_TRACE
+    if (first_trip) { WP_STAMP(2) first_trip = false; }
+#endif
   }
-  // fold the two K halves: waves 4..7 hand their accumulators to waves 0..3 through LDS (the operand tiles are dead)
-  float* red = &As[0][0][0];                          // [4][16][64] floats = 16 KB <= sizeof(As)
-  if (h == 1) {
+  WP_STAMP(3)
+  f32x16 acc = accs[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(q * 16 + r) * 64 + lane] = acc[r];
+  for (int c = 1; c < VTX_WP_NACC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += accs[c][r];
+  // fold the four K quarters in the order 0, 1, 2, 3: waves 1 .. 3 hand their accumulators to wave 0 through LDS
+  if (h > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[h - 1][r][lane] = acc[r];
+  }
+  if (with_y) {                                        // the lane pair (l, l + 32) holds the two k halves of row l % 32
+    const float other = __shfl_xor(yacc, 32, 64);
+    if (kh == 0) yred[h][li] = yacc + other;
   }
   __syncthreads();
+  WP_STAMP(4)
   if (h == 0) {
-    const int col = j0 + qj * 32 + (lane & 31);
-    const float vj = (p.u && col < p.N2) ? p.v[col] : 0.f;
+    const float vj = (p.u && col_ok) ? p.v[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = i0 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.N1 && col < p.N2) {
-        float val = p.alpha * (acc[r] + red[(q * 16 + r) * 64 + lane]);
-        if (p.u) val = fmaf(p.u[row], vj, val);
-        float* dst = p.C + (long)row * p.ldc + col;
+      const int orow = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (orow < p.N1 && col_ok) {
+        float val = p.alpha * (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]);
+        if (p.u) val = fmaf(p.u[orow], vj, val);
+        float* dst = p.C + (long)orow * p.ldc + col;
         if (p.accumulate) val += *dst;
         *dst = val;
       }
     }
-    if (with_y && wave == 0) {
-      const int row = i0 + lane;
-      if (row < p.N1) {
-        float val = p.alpha_y * yacc;
-        if (p.z) val = fmaf(p.beta_z, p.z[row], val);
-        if (p.y_accumulate) val += p.y[row];
-        p.y[row] = val;
-      }
+    if (with_y && kh == 0 && row_ok) {
+      float val = p.alpha_y * (((yred[0][li] + yred[1][li]) + yred[2][li]) + yred[3][li]);
+      if (p.z) val = fmaf(p.beta_z, p.z[row], val);
+      if (p.y_accumulate) val += p.y[row];
+      p.y[row] = val;
     }
   }
+  WP_STAMP(5)
 }
 
 }  // namespace vtx
@@ -168,8 +194,8 @@ extern "C" int vtx_wprod(const vtx_wprod_desc* d, void* stream) {
   VTX_REQUIRE((d->b_ks == 1) != (d->b_cs == 1), VTX_EINVAL, "wprod: exactly one stride of B must be 1 (b_ks=%ld b_cs=%ld)",
               d->b_ks, d->b_cs);
   const long a_ld = d->a_ks == 1 ? d->a_rs : d->a_ks, b_ld = d->b_ks == 1 ? d->b_cs : d->b_ks;
-  VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && a_ld % 4 == 0 && b_ld % 4 == 0, VTX_EALIGN,
-              "wprod: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  VTX_REQUIRE(aligned16(d->A) && aligned16(d->B) && a_ld % 4 == 0 && b_ld % 4 == 0 && (!d->x || aligned16(d->x)), VTX_EALIGN,
+              "wprod: operands (and x) must be 16-byte aligned with leading dimensions that are multiples of 4");
   VTX_REQUIRE(d->ldc >= d->N2, VTX_EINVAL, "wprod: ldc=%ld < N2=%d", d->ldc, d->N2);
   VTX_REQUIRE((d->u == nullptr) == (d->v == nullptr), VTX_EINVAL, "wprod: the rank-1 term needs both u and v");
   VTX_REQUIRE((d->y == nullptr) == (d->x == nullptr), VTX_EINVAL, "wprod: the vector product needs both x and y");
@@ -179,13 +205,30 @@ extern "C" int vtx_wprod(const vtx_wprod_desc* d, void* stream) {
   p.B = d->B; p.b_ks = d->b_ks; p.b_cs = d->b_cs;
   p.alpha = d->alpha; p.C = d->C; p.ldc = d->ldc; p.accumulate = d->accumulate;
   p.u = d->u; p.v = d->v;
+  p.trace = nullptr;
+#ifdef VTX_WP_TRACE
+  p.trace = reinterpret_cast<long long*>(options().pp_trace);
+#endif
   p.x = d->x; p.y = d->y; p.alpha_y = d->alpha_y; p.z = d->z; p.beta_z = d->beta_z; p.y_accumulate = d->y_accumulate;
   const dim3 grid(cdiv(d->N2, WP_T), cdiv(d->N1, WP_T)), block(WP_THREADS);
   hipStream_t st = as_stream(stream);
   const bool ak = d->a_ks == 1, bk = d->b_ks == 1;
-  if (ak && bk) hipLaunchKernelGGL((wprod_kernel<true, true>), grid, block, 0, st, p);
-  else if (ak) hipLaunchKernelGGL((wprod_kernel<true, false>), grid, block, 0, st, p);
-  else if (bk) hipLaunchKernelGGL((wprod_kernel<false, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((wprod_kernel<false, false>), grid, block, 0, st, p);
+  // (VTX_WP_PAD_KB: unused dynamic LDS as an occupancy limiter, an experiment: the dispatcher was suspected of filling CUs one by
+  // one; tools/micro/census.hip shows that it places the 576 workgroups 2 - 3 per CU whatever the limit, and 0 / 36 / 56 KB time the same)
+  const size_t pad = (size_t)VTX_WP_PAD_KB * 1024;
+  // FULL: whole tiles, and K a whole number of look-ahead trips of all four waves (no block beyond K is ever walked)
+  const bool full = d->N1 % 32 == 0 && d->N2 % 32 == 0 && d->K % (32 * WP_D) == 0, wx = d->x != nullptr;
+#define WP_LAUNCH(AK_, BK_)                                                                                          \
+  {                                                                                                                  \
+    if (full && wx) hipLaunchKernelGGL((wprod_kernel<AK_, BK_, true, true>), grid, block, pad, st, p);               \
+    else if (full) hipLaunchKernelGGL((wprod_kernel<AK_, BK_, true, false>), grid, block, pad, st, p);               \
+    else if (wx) hipLaunchKernelGGL((wprod_kernel<AK_, BK_, false, true>), grid, block, pad, st, p);                 \
+    else hipLaunchKernelGGL((wprod_kernel<AK_, BK_, false, false>), grid, block, pad, st, p);                        \
+  }
+  if (ak && bk) WP_LAUNCH(true, true)
+  else if (ak) WP_LAUNCH(true, false)
+  else if (bk) WP_LAUNCH(false, true)
+  else WP_LAUNCH(false, false)
+#undef WP_LAUNCH
   return check_launch("wprod");
 }

@@ -142,7 +142,7 @@ SIGNATURES = {
     'vtx_embed_table': (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     'vtx_hog_table_bytes': (sz, []),
     'vtx_hog_build_table': (ci, [vp]),
-    'vtx_hog_fwd': (ci, [vp, ci, ci, ci, vp, vp, vp, vp]),
+    'vtx_hog_fwd': (ci, [vp, ci, ci, ci, vp, sz, vp, vp, vp]),
     'vtx_maskfeat_blend_fwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     'vtx_maskfeat_blend_bwd': (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     'vtx_maskfeat_loss_fwd': (ci, [ci, ci, ci, ci, ci, ci, vp, cl, vp, vp, vp, vp]),

@@ -43,11 +43,19 @@ def all_reduce_sum(t, group=None):
 
 class GradBuckets:
     def __init__(self, params, bucket_bytes=48 << 20, process_group=None, comm_dtype=None, force_comm=False,
-                 direct=False):
+                 direct=False, static_unused=False):
         """direct=True: the block kernels accumulate parameter gradients straight into the bucket views (no
         per-parameter `grad += new` kernels; see vtx.functions.set_direct_grads) -- a process-wide switch that
-        stays on until set_direct_grads(False) or remove()."""
+        stays on until set_direct_grads(False) or remove().
+        static_unused=True: the parameters `unfired()` reports (no gradient on ANY rank) are taken to be unused in every later
+        step as well and no longer hold their bucket back: buckets go out in order, so ONE parameter without a gradient -- the
+        tail of a pretrain model such as MaskFeat's unused head -- otherwise keeps its bucket and every later one until
+        finish(), i.e. the whole exchange loses its overlap with backward.  Should such a parameter get a gradient
+        after all, it is counted again from the next step on; if its bucket has already gone out this step, the hook raises."""
         self.group = process_group
+        self.static_unused = bool(static_unused)
+        self._known_unused = set()               # id() of parameters every rank agreed are unused (static_unused)
+        self._warned_held = False
         self.direct = bool(direct)
         if self.direct:
             from . import functions
@@ -92,6 +100,15 @@ class GradBuckets:
     def _make_hook(self, bi):
         def hook(p):
             b = self.buckets[bi]
+            if id(p) in self._known_unused:
+                # a parameter all ranks had agreed is unused gets a gradient after all: it was not counted in `pending`
+                if bi < self._next:
+                    raise RuntimeError('GradBuckets(static_unused=True): a parameter that was unused in earlier steps received a '
+                                       'gradient after the all-reduce of its bucket had been issued -- the gradient would be lost; '
+                                       'build the buckets with static_unused=False for models whose graph changes between steps')
+                self._known_unused.discard(id(p))
+                self._fired.add(id(p))
+                return
             if id(p) in self._fired:
                 # direct gradients: the kernels' own call (vtx.functions._fire) came first; this torch version also
                 # runs a parameter's post-accumulate hooks when the Function returned None for it -- count once
@@ -148,7 +165,7 @@ class GradBuckets:
         the .grad views must stay bound to the buckets)."""
         for b in self.buckets:
             b['flat'].zero_()
-            b['pending'] = len(b['params'])
+            b['pending'] = sum(1 for p in b['params'] if id(p) not in self._known_unused)
             b['handle'] = None
             b['comm'] = None
         self._launched = []
@@ -160,6 +177,18 @@ class GradBuckets:
         """Wait for every bucket's all-reduce; afterwards param.grad holds the mean gradient."""
         # buckets that have not gone out yet (a parameter without a gradient this step holds its bucket -- and every later
         # one -- back): now, in bucket order, so that every rank issues the same sequence
+        held = len(self.buckets) - self._next
+        if held > 1 and (self.world > 1 or self.force_comm) and not self._warned_held:
+            # more than the one bucket backward has just completed: some parameter got no gradient this step and held its
+            # bucket -- and every later one -- back, so their all-reduces start only now, with no backward left to hide them
+            import sys
+            first = self.buckets[self._next]
+            names = sum(1 for p in first['params'] if id(p) not in self._fired)
+            sys.stderr.write(f'vtx.dp.GradBuckets: finish() had to issue {held} of {len(self.buckets)} all-reduces after backward '
+                             f'(bucket {self._next} waited for {names} parameter(s) without a gradient): no overlap with backward '
+                             'for them.  If those parameters are unused in every step, build the buckets with static_unused=True '
+                             'and call unfired() after finish() (reported once).\n')
+            self._warned_held = True
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next])
             self._next += 1
@@ -191,6 +220,8 @@ class GradBuckets:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             fired = flags.cpu().tolist()
         self._unfired_cache = [p for p, f in zip(params, fired) if not f]
+        if self.static_unused:                   # agreed across ranks: the same set everywhere
+            self._known_unused = {id(p) for p in self._unfired_cache}
         return self._unfired_cache
 
     def remove(self):

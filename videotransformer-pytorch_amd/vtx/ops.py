@@ -559,7 +559,7 @@ def hog_fwd(frames, want_bins=False):
     bins = torch.empty(F, 3, H, W, dtype=torch.int32, device=frames.device) if want_bins else None
     table = hog_table(frames.device)
     with _timed('hog', nbytes=frames.numel() + out.numel() * 8, key=f'{F}x{H}x{W}'):
-        call('vtx_hog_fwd', ptr(frames), F, H, W, ptr(table), ptr(out), ptr(bins), stream())
+        call('vtx_hog_fwd', ptr(frames), F, H, W, ptr(table), table.numel() * 8, ptr(out), ptr(bins), stream())
     return (out, bins) if want_bins else out
 
 
