@@ -62,7 +62,9 @@ int vtx_version(void);
 const char* vtx_last_error_string(void);
 /* Tuning / diagnostic switches (process-wide; initial values from the VTX_* environment variables,
  * read once): "gemm_nt" = auto|pp256|dma2|ring128x3|ring128x4k32|ring256x3|ring256x3k32|ring256x4k32,
- * "gemm_tn" = auto|pp256|ring|dma2|w4, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "attn_hw_fwd", "attn_hw_bwd" = n
+ * "gemm_tn" = auto|pp256|ring|dma2|w4, "gemm_nodma", "tn_safe", "attn_valu" = 0|1, "tn_cus" = n (compute units the weight-gradient
+ * kernel's one-round slab split is sized for: 256; 240 leaves room for 16 CUs held by a collective in flight -- another, equally fixed
+ * summation order of the slabs), "attn_hw_fwd", "attn_hw_bwd" = n
  * (short-sequence attention: n heads of a row tile per workgroup, 0 = one head and four row tiles; defaults 16 / 4), "pp_grid", "pp_cg",
  * "pp_epi" = integers ("pp_epi": 1 = per-pass epilogue of the persistent GEMM; 2 / 3 = timing diagnostics that skip
  * its stores / its LDS staging and produce WRONG output; 4 = the general passes instead of the lean ones of the

@@ -24,7 +24,7 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-_OPTION_DEFAULTS = dict(gemm_nt='auto', gemm_tn='auto', gemm_nodma='0', tn_safe='0', attn_valu='0', attn_hw_fwd='16', attn_hw_bwd='4', pp_grid='256',
+_OPTION_DEFAULTS = dict(gemm_nt='auto', gemm_tn='auto', gemm_nodma='0', tn_safe='0', tn_cus='256', attn_valu='0', attn_hw_fwd='16', attn_hw_bwd='4', pp_grid='256',
                         pp_cg='0', pp_epi='0', pp_cont='1', attn_fused='2', attn_fwd_stream='1', attn_dkv='3', ln_rows='3')
 
 

@@ -1,12 +1,22 @@
 """Round-6 golden from the UNMODIFIED reference (dev container only: needs /root/reference):
 
-    python tests/golden/make_golden_r6.py [tsf_l_t96_full] [autocast]
+    python tests/golden/make_golden_r6.py [tsf_l_t96_full] [autocast] [attn_cal]
+
+  autocast_cal.json: 'TimeSformer-B T=8 attention' -- the attention-map slice tests/test_gpu_00_baseline_configs.py compares
+                           (get_last_selfattention[:2, :, :8, :8] of TimeSformer-B 8x224^2): the deviation of the reference's own
+                           torch.autocast(bfloat16) run from its fp32 run ('out'), and of the autocast run with its residual stream
+                           rounded to bf16 after every sub-block ('out_bf16_stream': the storage decision of the HIP path).
 
   tsf_l_t96_d24_eval.npz   BASELINE.json configs[4] at FULL depth: TimeSformer-L (D 1024, 16 heads, 24 layers) on one 96x3x224x224
                            clip, eval-mode forward -- 18 817 tokens through 24 layers (~17 TFLOP on the CPU).  VERDICT r5 item 7c:
                            the only TimeSformer-L golden so far was depth 2; 24 layers of bf16 residual stream is where accumulated
                            rounding would show.  'out' = the reference's fp32 features [1, 1024]; with `autocast` also
-                           'out_autocast' = the reference's own torch.autocast(bfloat16) run (the yardstick for the bf16 path).
+                           'out_autocast' = the reference's own torch.autocast(bfloat16) run (the yardstick for the bf16 path), and
+                           'out_autocast_bf16_stream' = the same autocast run with every sub-block's output (3 per layer) rounded to
+                           bf16 by forward hooks -- the reference's arithmetic under the ONE storage decision in which the HIP path
+                           differs from autocast (the residual stream is stored as bf16; autocast keeps it in
+                           float32).  Measured: 5.0e-3 / 1.43e-2 at depth 24 (5.5e-3 / 1.05e-2 at depth 12, tools/precision_study_l96.py):
+                           the stream's rounding grows with sqrt(depth) and is what the bf16 path is held against at this depth.
 """
 import os
 import sys
@@ -22,10 +32,34 @@ from oracle import ref_loader, synth  # noqa: E402
 
 
 def main():
-    which = sys.argv[1:] or ['tsf_l_t96_full', 'autocast']
+    which = sys.argv[1:] or ['tsf_l_t96_full', 'autocast', 'attn_cal']
     VT = ref_loader.load().video_transformer
     torch.set_num_threads(os.cpu_count())
     path = os.path.join(HERE, 'tsf_l_t96_d24_eval.npz')
+    if 'attn_cal' in which:
+        import json
+        m = VT.TimeSformer(num_frames=8)
+        m.load_state_dict(synth.synth_state_dict(synth.shapes_of(m), seed=0), strict=True)
+        m.eval()
+        x = synth.synth_clip(1, 8, seed=1)
+        h32 = torch.from_numpy(np.load(os.path.join(HERE, 'tsf_b_t8_eval.npz'))['attn_head'])
+
+        def slice_dev(stream_bf16):
+            hooks = []
+            if stream_bf16:
+                for layer in m.transformer_layers.layers:
+                    for sub in list(layer.attentions) + list(layer.ffns):
+                        hooks.append(sub.register_forward_hook(lambda mod, inp, out: out.float().bfloat16().float() if torch.is_tensor(out) else out))
+            with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+                a = m.get_last_selfattention(x).float()[:2, :, :8, :8]
+            for h in hooks:
+                h.remove()
+            return float((a - h32).abs().max() / h32.abs().max())
+        cal_path = os.path.join(HERE, 'autocast_cal.json')
+        cal = json.load(open(cal_path))
+        cal['TimeSformer-B T=8 attention'] = {'out': slice_dev(False), 'out_bf16_stream': slice_dev(True), 'grad': {}}
+        print('TimeSformer-B T=8 attention', cal['TimeSformer-B T=8 attention'], flush=True)
+        json.dump(cal, open(cal_path, 'w'), indent=0, sort_keys=True)
     if 'tsf_l_t96_full' in which:
         m = VT.TimeSformer(num_frames=96, embed_dims=1024, num_heads=16, num_transformer_layers=24)
         sd = synth.synth_state_dict(synth.shapes_of(m), seed=0)
@@ -45,6 +79,16 @@ def main():
                 yac = m(x).float()
             res['out_autocast'] = yac.numpy()
             print('tsf_l_t96_d24_eval autocast', f'{time.time() - t0:.0f} s', 'deviation', float((yac - y).abs().max() / y.abs().max()), flush=True)
+            hooks = []
+            for layer in m.transformer_layers.layers:
+                for sub in list(layer.attentions) + list(layer.ffns):
+                    hooks.append(sub.register_forward_hook(lambda mod, inp, out: out.float().bfloat16().float() if torch.is_tensor(out) else out))
+            with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+                ys = m(x).float()
+            for h in hooks:
+                h.remove()
+            res['out_autocast_bf16_stream'] = ys.numpy()
+            print('tsf_l_t96_d24_eval autocast + bf16 stream deviation', float((ys - y).abs().max() / y.abs().max()), flush=True)
             np.savez_compressed(path, **res)
 
 

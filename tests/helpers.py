@@ -30,10 +30,17 @@ NS = 4096                  # samples per large tensor in the round-2 goldens
 # reference): what the reference's own torch.autocast(bfloat16) run deviates from its fp32 run on exactly this case, same
 # metric.  A bf16 check that names its case gets the bar  max(fixed bar, AUTOCAST_FACTOR * reference deviation):  the fixed
 # bars above stay the floor (no case gets tighter or looser unless the reference itself is noisier than half the bar on it).
-# Only 'tsf other resolution (64, 96)' is: the reference deviates by 1.334e-2 there (a maximum over 256 output values of a
-# two-layer model; 6.2e-3 / 5.3e-3 on its two neighbours, 4.2e-3 ... 1.1e-2 over twelve other weight seeds,
+# Among the OUTPUT bars only 'tsf other resolution (64, 96)' moves: the reference deviates by 1.334e-2 there (a maximum over 256
+# output values of a two-layer model; 6.2e-3 / 5.3e-3 on its two neighbours, 4.2e-3 ... 1.1e-2 over twelve other weight seeds,
 # profiles/round5_other_resolution_seeds.txt), so the fixed 1.5e-2 sat 13 % above the reference's own noise and
 # a summation-order change in an fp32 weight product (wprod K tiles, round 4) moved this path across it.
+# GRADIENT bars are widened PER TENSOR by the same rule: every tensor on which the reference's autocast run deviates by more than
+# 1e-2 gets max(2e-2, 2 x that deviation) -- e.g. tsf_small divided_space_time at 1.27e-2 -> 2.5e-2, and the other-resolution
+# gradients (the earlier wording "only one case" was about the outputs).  Round 6: a widened bar is CAPPED at WIDEN_CAP x
+# the fixed bar (2.25e-2 for outputs, 3e-2 for gradients; the element bar scales with it), and the median of a case's gradient
+# errors is held against 1.25 x the reference-autocast median whenever a calibration is given -- widening a tensor's bar can no
+# longer hide a regression of the typical tensor.
+WIDEN_CAP = 1.5
 _CAL = None
 
 
@@ -76,7 +83,7 @@ def check(name, got, ref, tol, cal=None, widen=True):
     if cal is not None:
         ae = cal_entry(cal)['out']
         if widen:
-            tol = max(tol, AUTOCAST_FACTOR * ae)
+            tol = max(tol, min(AUTOCAST_FACTOR * ae, WIDEN_CAP * tol))
         extra = f'; reference autocast {ae:.3e}'
     report(f'{"ok  " if e <= tol else "FAIL"} {name}: rel={e:.3e} (tol {tol:g}{extra})')
     assert e <= tol, f'{name}: rel err {e:.3e} > {tol:g}'
@@ -136,7 +143,7 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_ca
         worst_l2, worst_max = max(worst_l2, e_l2), max(worst_max, e_max)
         tol_k = tol
         if cal_grad is not None:
-            tol_k = max(tol, AUTOCAST_FACTOR * cal_grad[name]) if widen else tol
+            tol_k = max(tol, min(AUTOCAST_FACTOR * cal_grad[name], WIDEN_CAP * tol)) if widen else tol
             ours.append(e_l2)
             theirs.append(cal_grad[name])
         lim_max = tol_k if exact_elements else ELEMENT_SLACK * tol_k
@@ -153,7 +160,9 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_ca
     if ours:
         mo, mt = sorted(ours)[len(ours) // 2], sorted(theirs)[len(theirs) // 2]
         extra = f'; median l2 {mo:.3e} vs reference-autocast median {mt:.3e} (worst {max(theirs):.3e})'
-        if autocast_cal:
+        if autocast_cal or cal_grad is not None:
+            if mo > 1.25 * mt:
+                report(f'FAIL {prefix}: median gradient error {mo:.3e} > 1.25 x the reference autocast median {mt:.3e}')
             assert mo <= 1.25 * mt, f'{prefix}: median gradient error {mo:.3e} > 1.25 x the reference autocast median {mt:.3e}'
     report(f'ok   {prefix}: {n} parameter gradients, worst max-rel={worst_max:.3e} l2-rel={worst_l2:.3e} (tol {tol:g}){extra}')
     return worst_max

@@ -90,8 +90,11 @@ def test_unused_parameters_take_no_update():
     assert steps[0] == 5.0 and steps[1] == 3.0 and 4 not in steps, steps
     assert {i: float(st['step']) for i, st in o_ref.state_dict()['state'].items()} == steps
     sd = o_gpu.state_dict()
-    assert all('step' not in st for st in o_gpu.state.values()), "state_dict() must not leave a 'step' key in the live state"
-    assert all('step' in st for st in sd['state'].values())
+    # round 6: the update count lives where torch keeps it, in the parameter's own state entry (a plain int in the live
+    # state: it survives whatever happens to id(parameter)); state_dict() hands it out as one tensor per parameter
+    assert all(isinstance(st['step'], int) for st in o_gpu.state.values() if 'step' in st)
+    assert all(torch.is_tensor(st['step']) for st in sd['state'].values())
+    assert o_gpu.state[p_gpu[1]]['step'] == 3 and 'step' not in o_gpu.state.get(p_gpu[4], {})
 
 
 @pytest.mark.parametrize('kind', ['sgd', 'adamw'])

@@ -8,7 +8,10 @@ what a channel of a collective does to them -- for the whole measurement, and th
 bench.py) is timed with HIP events per GEMM launch.  H = 0 / 8 / 16 / 32.  The hold is CONTINUOUS here; in the real job a
 collective is in flight for 3 - 9 % of the backward, so the step-level cost scales by that duty cycle.
 
-    python tools/cu_contention.py [--batch 96] [--steps 6] [--holds 0,8,16,32,0]
+    python tools/cu_contention.py [--batch 96] [--steps 6] [--holds 0,8,16,32,0] [--tn-cus 256,240]
+
+--tn-cus: values of the option `tn_cus` (CUs the weight-gradient kernel's slab split is sized for; 240 = room for 16 held CUs) to
+repeat the sweep with.
 """
 import ctypes
 import os
@@ -37,6 +40,7 @@ def main():
     opt = lambda name, d: sys.argv[sys.argv.index(name) + 1] if name in sys.argv else d      # noqa: E731
     B, steps = int(opt('--batch', 96)), int(opt('--steps', 6))
     holds = [int(v) for v in opt('--holds', '0,8,16,32,0').split(',')]
+    tn_cus_list = [int(v) for v in opt('--tn-cus', '256').split(',')]
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     import vtx
@@ -73,44 +77,47 @@ def main():
     print(f'TimeSformer-B 8x224^2, {B} clips, bf16 step (fwd + CE + bwd + SGD), {steps} timed steps per setting; holder = one 256-thread '
           f'workgroup per held CU on a side stream for the whole measurement')
     print(f'{"held CUs":>8s} {"distinct CUs":>12s} {"ms/step":>8s} {"clips/s":>8s} {"vs 0":>7s} | {"NT us":>7s} {"vs 0":>6s} | {"TN us":>7s} {"vs 0":>6s} | TN per shape (us)')
-    base = None
-    for H in holds:
-        stop = torch.zeros(1, dtype=torch.int32, device=dev)
-        census = torch.zeros(2 * max(H, 1), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        if H:
-            rc = lib.cu_hold_launch(H, 20.0, stop.data_ptr(), census.data_ptr(), side.cuda_stream)
-            assert rc == 0, rc
-            time.sleep(0.05)                                  # the holders are resident before the first kernel of the step
-        step()                                               # one untimed step under the same condition
-        ops.profile_start(('gemm_nt', 'gemm_tn'))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            step()
-        e1.record()
-        e1.synchronize()
-        prof = ops.profile_stop()
-        with torch.cuda.stream(side2):
-            stop.fill_(1)
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / steps
-        tot = ops.profile_totals(prof)
-        nt_us = tot['gemm_nt'][1] / tot['gemm_nt'][0] * 1e3
-        tn_us = tot['gemm_tn'][1] / tot['gemm_tn'][0] * 1e3
-        cz = census.cpu().numpy().astype('uint32')
-        distinct = len({(int(cz[2 * i]) & 0xF, int(cz[2 * i + 1]) & 0xFF00) for i in range(H)}) if H else 0
-        shapes = {}
-        for key, (n, tms, fl, by) in prof['gemm_tn'].items():
-            _, n1, n2 = key.split('x')
-            r = shapes.setdefault(f'{n1}x{n2}', [0, 0.0])
-            r[0] += n
-            r[1] += tms
-        per = '  '.join(f'{k} {v[1] / v[0] * 1e3:.0f}' for k, v in sorted(shapes.items()))
-        if base is None:
-            base = (ms, nt_us, tn_us)
-        print(f'{H:8d} {distinct:12d} {ms:8.2f} {B / ms * 1e3:8.1f} {ms / base[0]:7.3f} | {nt_us:7.1f} {nt_us / base[1]:6.3f} | {tn_us:7.1f} {tn_us / base[2]:6.3f} | {per}',
-              flush=True)
+    for tn_cus in tn_cus_list:
+        vtx.set_option('tn_cus', str(tn_cus))
+        print(f'-- option tn_cus = {tn_cus}')
+        base = None
+        for H in holds:
+            stop = torch.zeros(1, dtype=torch.int32, device=dev)
+            census = torch.zeros(2 * max(H, 1), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            if H:
+                rc = lib.cu_hold_launch(H, 20.0, stop.data_ptr(), census.data_ptr(), side.cuda_stream)
+                assert rc == 0, rc
+                time.sleep(0.05)                                  # the holders are resident before the first kernel of the step
+            step()                                               # one untimed step under the same condition
+            ops.profile_start(('gemm_nt', 'gemm_tn'))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                step()
+            e1.record()
+            e1.synchronize()
+            prof = ops.profile_stop()
+            with torch.cuda.stream(side2):
+                stop.fill_(1)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            tot = ops.profile_totals(prof)
+            nt_us = tot['gemm_nt'][1] / tot['gemm_nt'][0] * 1e3
+            tn_us = tot['gemm_tn'][1] / tot['gemm_tn'][0] * 1e3
+            cz = census.cpu().numpy().astype('uint32')
+            distinct = len({(int(cz[2 * i]) & 0xF, int(cz[2 * i + 1]) & 0xFF00) for i in range(H)}) if H else 0
+            shapes = {}
+            for key, (n, tms, fl, by) in prof['gemm_tn'].items():
+                _, n1, n2 = key.split('x')
+                r = shapes.setdefault(f'{n1}x{n2}', [0, 0.0])
+                r[0] += n
+                r[1] += tms
+            per = '  '.join(f'{k} {v[1] / v[0] * 1e3:.0f}' for k, v in sorted(shapes.items()))
+            if base is None:
+                base = (ms, nt_us, tn_us)
+            print(f'{H:8d} {distinct:12d} {ms:8.2f} {B / ms * 1e3:8.1f} {ms / base[0]:7.3f} | {nt_us:7.1f} {nt_us / base[1]:6.3f} | {tn_us:7.1f} {tn_us / base[2]:6.3f} | {per}',
+                  flush=True)
 
 
 if __name__ == '__main__':

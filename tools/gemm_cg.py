@@ -6,7 +6,7 @@ import torch
 import vtx
 from vtx import ops
 from kernel_bench import timeit
-M = 100352
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 100352
 for (N, K) in ((3072, 768), (2304, 768), (768, 3072), (768, 2304), (768, 768)):
     a = torch.randn(M, K, device='cuda').bfloat16()
     w = torch.randn(N, K, device='cuda').bfloat16()

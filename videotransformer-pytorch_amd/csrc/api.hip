@@ -42,6 +42,7 @@ static int set_option(Options& o, const char* name, const char* value) {
   if (strcmp(name, "gemm_tn") == 0) { const int e = parse_enum(value, kTnNames, 5); if (e < 0) return VTX_EINVAL; o.gemm_tn = e; return VTX_OK; }
   if (strcmp(name, "gemm_nodma") == 0) { o.gemm_nodma = atoi(value) != 0; return VTX_OK; }
   if (strcmp(name, "tn_safe") == 0) { o.tn_safe = atoi(value) != 0; return VTX_OK; }
+  if (strcmp(name, "tn_cus") == 0) { const int g = atoi(value); if (g < 32 || g > 1024) return VTX_EINVAL; o.tn_cus = g; return VTX_OK; }
   if (strcmp(name, "attn_valu") == 0) { o.attn_valu = atoi(value) != 0; return VTX_OK; }
   if (strcmp(name, "attn_hw_fwd") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.attn_hw_fwd = g; return VTX_OK; }
   if (strcmp(name, "attn_hw_bwd") == 0) { const int g = atoi(value); if (g < 0) return VTX_EINVAL; o.attn_hw_bwd = g; return VTX_OK; }
@@ -61,7 +62,7 @@ Options& options() {
   static Options o = [] {
     Options d;
     static const char* const env[][2] = {{"VTX_GEMM_NT", "gemm_nt"}, {"VTX_GEMM_TN", "gemm_tn"}, {"VTX_GEMM_NODMA", "gemm_nodma"},
-                                         {"VTX_TN_SAFE", "tn_safe"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
+                                         {"VTX_TN_SAFE", "tn_safe"}, {"VTX_TN_CUS", "tn_cus"}, {"VTX_ATTN_VALU", "attn_valu"}, {"VTX_GEMM_PP_GRID", "pp_grid"},
                                          {"VTX_GEMM_PP_CG", "pp_cg"}, {"VTX_GEMM_PP_EPI", "pp_epi"},
                                          {"VTX_GEMM_PP_CONT", "pp_cont"}, {"VTX_LN_ROWS", "ln_rows"}, {"VTX_ATTN_HW_FWD", "attn_hw_fwd"}, {"VTX_ATTN_HW_BWD", "attn_hw_bwd"}, {"VTX_ATTN_DKV", "attn_dkv"}, {"VTX_ATTN_FWD_STREAM", "attn_fwd_stream"},
                                          {"VTX_ATTN_FUSED", "attn_fused"}};

@@ -169,6 +169,11 @@ struct Options {
   int gemm_tn = TN_AUTO;     // VTX_GEMM_TN: ... of vtx_gemm_tn (bf16)
   int gemm_nodma = 0;        // VTX_GEMM_NODMA: register-staged GEMM kernels (no LDS-DMA)
   int tn_safe = 0;           // VTX_TN_SAFE: bounds-checked TN loader (diagnostic)
+  int tn_cus = 256;          // VTX_TN_CUS: compute units the weight-gradient kernel's one-round slab split is sized for.  Its workgroups
+                             // own a CU each; with fewer CUs free than workgroups (an RCCL collective in flight holds some) the launch
+                             // runs a second, nearly empty round (1.4 - 1.6x, profiles/round6_cu_contention.txt).  240 keeps it to one
+                             // round with up to 16 CUs held, at +4 .. 7 % per launch when none is.  Changes the slab partition, i.e. the
+                             // fp32 summation order of the weight gradients (still fixed for a given value: bit-reproducible).
   int attn_valu = 0;         // VTX_ATTN_VALU: fp32-VALU attention kernels also for bf16
   int attn_hw_fwd = 16;      // VTX_ATTN_HW_FWD / _BWD: short-sequence attention with n heads of a row tile in one workgroup
   int attn_hw_bwd = 4;       //   (0: one head per workgroup, four row tiles; backward: 4 heads -- 512 contiguous bytes per row -- measured best)

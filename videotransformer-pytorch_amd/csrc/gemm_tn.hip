@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(TW_THREADS, 1) void gemm_tn_bf16_w4_kernel(
 
 static int tp_splits(int M, int N1, int N2) {
   const int tiles = cdiv(N1, 256) * cdiv(N2, 256);
-  int s = 256 / tiles;                          // one workgroup per CU
+  int s = options().tn_cus / tiles;             // one workgroup per CU (option tn_cus: 256 unless the caller reserves CUs, common.h)
   const int max_s = M / 128;                    // every split spans >= 2 K tiles
   if (s > max_s) s = max_s;
   return s < 1 ? 1 : s;

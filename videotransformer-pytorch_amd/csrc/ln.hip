@@ -472,6 +472,43 @@ __global__ __launch_bounds__(256) void reduce_partials_v4_kernel(const float* __
   }
 }
 
+// Few columns, many slabs (the LayerNorm backward: 2 D = 1536 columns of up to 1024 per-block partial rows): the kernel above would
+// run 24 blocks, each lane adding 256 values one behind the other (17.5 us for 6 MB, latency-bound on 24 CUs).  Here a block is 64
+// columns x 16 slab lanes: a lane adds nslabs / 16 values (four independent chains), the 16 lane sums are folded through LDS in a
+// fixed order.  Deterministic; another (equally fixed) summation order than the 4-lane kernel.  No folded copies (fold == 1).
+__global__ __launch_bounds__(1024) void reduce_partials_wide_kernel(const float* __restrict__ part, int nslabs, long stride,
+                                                                    long N, float* __restrict__ out, int accumulate, float scale,
+                                                                    float* __restrict__ out2, long split, int accumulate2) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  const long n = (long)blockIdx.x * 64 + cx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (n < N) {
+    int s = sy;
+    for (; s + 48 < nslabs; s += 64) {
+      a0 += part[(long)s * stride + n];
+      a1 += part[(long)(s + 16) * stride + n];
+      a2 += part[(long)(s + 32) * stride + n];
+      a3 += part[(long)(s + 48) * stride + n];
+    }
+    for (; s < nslabs; s += 16) a0 += part[(long)s * stride + n];
+  }
+  red[sy][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sy == 0 && n < N) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a += red[w][cx];
+    a *= scale;
+    if (out2 != nullptr && n >= split) {
+      float* o = out2 + (n - split);
+      *o = accumulate2 ? *o + a : a;
+    } else {
+      out[n] = accumulate ? out[n] + a : a;
+    }
+  }
+}
+
 int launch_reduce_partials(const float* part, int nslabs, long stride, long N, float* out,
                            int accumulate, float scale, hipStream_t st, float* out2, long split, int accumulate2,
                            int fold, long fold_stride) {
@@ -485,6 +522,11 @@ int launch_reduce_partials(const float* part, int nslabs, long stride, long N, f
     hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3(vec_blocks + tail_blocks), dim3(256), 0, st, part, nslabs, stride, N, nvec,
                        vec_blocks, out, accumulate, scale, out2, split, accumulate2, fold, fold_stride);
     return check_launch("reduce_partials_v4");
+  }
+  if (fold <= 1 && nslabs >= 128 && N <= 4096) {       // few columns, many slabs: 16 slab lanes per column
+    hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, st, part, nslabs, stride, N, out, accumulate,
+                       scale, out2, split, accumulate2);
+    return check_launch("reduce_partials_wide");
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, part, nslabs,
                      stride, N, out, accumulate, scale, out2, split, accumulate2, fold, fold_stride);

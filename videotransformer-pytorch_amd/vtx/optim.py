@@ -27,20 +27,24 @@ class _FusedBase(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.clip_grad = clip_grad
         self.last_grad_norm = None                      # device scalar: ||(per-parameter norms)||_2 of the last step
-        self._key = None
-        self._tables = []
-        self._steps = {}                                # id(parameter) -> number of updates it has taken (torch: state[p]['step'])
+        # device tables by partition key (the data pointers of a launch's parameters / gradients): a model whose set of unused
+        # parameters changes from step to step, or whose AdamW step counts split it into several launches, alternates between a
+        # few partitions -- each keeps its table and device buffers instead of being rebuilt (allocations + blocking copies) on
+        # every change, twice per step with clipping
+        self._table_cache = {}
         self._skipped = frozenset()                     # id() of parameters that take no update (see set_skipped)
+
+    def _step_of(self, p):
+        """Number of updates ``p`` has taken: kept where torch keeps it, in ``self.state[p]['step']`` (a plain int here) -- it
+        lives and dies with the parameter's state entry, whatever happens to the parameter object's id()."""
+        return int(self.state[p].get('step', 0))
 
     def set_skipped(self, params):
         """Parameters that received NO gradient in the step at hand.  With gradient buckets every ``p.grad`` is a (zero-filled)
         view that is never None, so "unused this step" has to be said explicitly: torch's optimizers skip ``grad is None``
         parameters altogether -- no weight decay, no momentum update -- and so does the step after this call (the reference runs
         DDP with find_unused_parameters=True for such models, model_pretrain.py:200-204)."""
-        ids = frozenset(id(p) for p in params)
-        if ids != self._skipped:
-            self._skipped = ids
-            self._key = None
+        self._skipped = frozenset(id(p) for p in params)      # (the tables are looked up by the entries that remain: no rebuild)
 
     # ---- device tables --------------------------------------------------------------------------
     def _entries(self):
@@ -94,20 +98,25 @@ class _FusedBase(torch.optim.Optimizer):
         ent = self._entries()
         if not ent:
             return []
-        parts = self._partition(ent)
-        key = tuple(tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p, _ in part) for part in parts)
-        if key != self._key:
-            self._tables = [self._build(part) for part in parts]
-            self._key = key
+        tables = []
+        for part in self._partition(ent):
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), gi) for p, gi in part)
+            t = self._table_cache.get(key)
+            if t is None:
+                if len(self._table_cache) >= 16:        # bounded: drop the oldest partition
+                    self._table_cache.pop(next(iter(self._table_cache)))
+                t = self._build(part)
+                self._table_cache[key] = t
+            tables.append(t)
         hyper = tuple((float(g['lr']), float(g['weight_decay'])) for g in self.param_groups)
-        for t in self._tables:
+        for t in tables:
             if hyper != t.hyper:                        # schedulers rewrite lr / weight_decay between steps
                 for i, gi in enumerate(t.groups_of):
                     t.tab_host[i].lr, t.tab_host[i].wd = hyper[gi]
                 raw = bytes(t.tab_host)
                 t.tab_dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8), non_blocking=False)
                 t.hyper = hyper
-        return self._tables
+        return tables
 
     def grad_norm(self):
         """||(||g_0||, ||g_1||, ...)||_2 over the parameters that have gradients, as a device scalar -- what
@@ -136,8 +145,8 @@ class _FusedBase(torch.optim.Optimizer):
             self.last_grad_norm = self.grad_norm()
         for t in tables:
             for p in t.params:
-                self._steps[id(p)] = self._steps.get(id(p), 0) + 1
-            self._launch(t, clip, self._steps[id(t.params[0])])
+                self.state[p]['step'] = self._step_of(p) + 1
+            self._launch(t, clip, self._step_of(t.params[0]))
         self._bump_versions()
         # the staged bf16 W / W^T copies of the updated weights: one launch now instead of one per weight in the next forward
         from . import functions
@@ -164,27 +173,22 @@ class _FusedBase(torch.optim.Optimizer):
     # move between these classes and torch.optim.SGD / AdamW.
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
-        self._key = None
+        self._table_cache = {}
 
     def state_dict(self):
         sd = super().state_dict()
         # torch packs the LIVE per-parameter dicts by reference: add the 'step' entry to shallow copies, or every save would leave
         # a stale key in the optimizer's own state.  One tensor PER parameter: torch.optim.AdamW increments each parameter's
         # 'step' in place after loading such a dict -- a shared tensor would count every parameter's update.
-        index_of = {}
-        for group in self.param_groups:                 # torch numbers the parameters in param_groups order
-            for p in group['params']:
-                index_of[len(index_of)] = p
-        sd['state'] = {k: {**v, 'step': torch.tensor(float(self._steps.get(id(index_of[k]), 0)))} for k, v in sd['state'].items()}
+        sd['state'] = {k: {**v, 'step': torch.tensor(float(v.get('step', 0)))} for k, v in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._steps = {}
         for p, st in self.state.items():
             if 'step' in st:
-                self._steps[id(p)] = int(float(st.pop('step')))
-        self._key = None                                # the loaded state tensors are new tensors
+                st['step'] = int(float(st['step']))
+        self._table_cache = {}                          # the loaded state tensors are new tensors
 
 
 class FusedSGD(_FusedBase):
@@ -234,7 +238,7 @@ class FusedAdamW(_FusedBase):
     def _partition(self, ent):
         by_step = {}
         for e in ent:
-            by_step.setdefault(self._steps.get(id(e[0]), 0), []).append(e)
+            by_step.setdefault(self._step_of(e[0]), []).append(e)
         return [by_step[k] for k in sorted(by_step, reverse=True)]
 
     def _launch(self, t, clip, step):
