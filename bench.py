@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=96, help='clips per GPU (weak scaling)')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--stream', default='bf16', choices=['bf16', 'fp32'],
+                    help="residual stream of the bf16 path: bf16 (default, the headline) or fp32 = vtx.set_stream('fp32'), the exact stream (DESIGN.md 3)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true', help='skip the instrumented per-kernel-class pass')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -308,6 +310,14 @@ def other_configs(dev, model8, head8, budget_s=40.0):
     for b in (8, 32):
         run('TimeSformer-B divided_space_time, 8x3x224x224, bf16, fwd+CE+bwd+SGD (headline model, %d clips per GPU)' % b,
             classifier(model8, head8), b, 8, FLOPS_FWD_BWD_PER_CLIP[8])
+    # the headline model and batch with the EXACT residual stream (vtx.set_stream('fp32'): the running sum of the residual stream in
+    # float32 as under the reference's autocast) -- what the accuracy mode costs
+    vtx.set_stream('fp32')
+    try:
+        run("TimeSformer-B divided_space_time, 8x3x224x224, bf16 with the exact float32 residual stream (vtx.set_stream('fp32')), fwd+CE+bwd+SGD, 96 clips per GPU",
+            classifier(model8, head8), 96, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=4, warmup=2)
+    finally:
+        vtx.set_stream('bf16')
     run('TimeSformer-B divided_space_time, 16x3x224x224, bf16, fwd+CE+bwd+SGD (north_star second shape)',
         classifier(*fresh(lambda: V.TimeSformer(num_frames=16))), 48, 16, FLOPS_FWD_BWD_PER_CLIP[16])
     run('ViViT-B fact_encoder, Conv3d tubelet 2, 16x3x224x224, bf16, fwd+CE+bwd+SGD (BASELINE configs[2])',
@@ -378,6 +388,7 @@ def main():
     import video_transformer as V
 
     vtx.set_precision(args.precision)
+    vtx.set_stream(args.stream)
     torch.manual_seed(0)
     model = V.TimeSformer(num_frames=args.frames)
     head = T.ClassificationHead(400, model.embed_dims)
@@ -459,7 +470,7 @@ def main():
         classes['_step_ms'] = step_ms
         classes['_steps'] = nb
     others = None
-    if world == 1 and not force_dp and not args.no_other_configs and args.precision == 'bf16' and args.frames == 8:
+    if world == 1 and not force_dp and not args.no_other_configs and args.precision == 'bf16' and args.frames == 8 and args.stream == 'bf16':
         buckets.remove()                                # the mini-runs build their own buckets over the same parameters
         del x
         torch.cuda.empty_cache()
@@ -484,7 +495,7 @@ def main():
             'config': {'workload': 'TimeSformer-B divided_space_time, %d frames x 3x224x224, %s, fwd+CE+bwd%s, '
                                    'random-init weights' % (args.frames, args.precision,
                                                             '' if args.no_optimizer else '+SGD(nesterov, %s)' % args.optimizer),
-                       'clips_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'clips_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'residual_stream': args.stream,
                        'grad_exchange': 'RCCL all-reduce (world size %d), per-layer fp32 buckets overlapped with backward' % rccl_world
                        if (world > 1 or force_dp) else 'none'},
             'clips_per_sec_per_gpu': round(value / world, 3),

@@ -46,6 +46,7 @@ extern "C" {
 
 #define VTX_F32 0
 #define VTX_BF16 1
+#define VTX_BF16_X32 3    /* vtx_layernorm_bwd only: bf16 gradients, x stored as float32 (the exact residual stream, vtx_layernorm_acc_fwd) */
 
 typedef struct {
   int grp;   /* rows per group (<=0: no groups) */
@@ -87,7 +88,18 @@ int vtx_set_option(const char* name, const char* value);
 int vtx_layernorm_fwd(int dtype, int rows, int D, const void* x, long ldx, vtx_rowmap xmap,
                       const float* gamma, const float* beta, float eps,
                       void* y, long ldy, vtx_rowmap ymap, float* mean, float* rstd, void* stream);
-/* dx[xmap(m)] = (dres ? dres[xmap(m)] : 0) + LN'(dy[m]);  dgamma/dbeta += column sums.
+/* The exact residual stream (library version 220; vtx.set_stream('fp32')).  The bf16 path stores the stream x as bf16 and every
+ * sub-block's x + f(x) is rounded: 3 roundings per layer in series, an error of the SUM that grows with sqrt(depth) (at 24 layers 3x
+ * the deviation of the reference's own torch.autocast run, which keeps the stream in float32: transformer.py:275,380,522 add in
+ * float32 under autocast).  In this mode a sub-block hands on its contribution d = f(x) (bf16: the residual GEMM's epilogue without
+ * the residual) and the stream lives in float32, advanced by the LayerNorm of the NEXT sub-block:
+ *     xo[omap(m)] = (xs ? xs[smap(m)] : 0) + d[smap(m)]          float32
+ *     y[ymap(m)]  = LayerNorm(row xo) * gamma + beta              bf16; y == NULL: accumulate only (rows no LayerNorm covers)
+ * xs, d share the leading dimension lds (the stream layout); mean / rstd as in vtx_layernorm_fwd.  bf16 compute only. */
+int vtx_layernorm_acc_fwd(int rows, int D, const float* xs, const void* d, long lds, vtx_rowmap smap, float* xo, long ldo,
+                          vtx_rowmap omap, const float* gamma, const float* beta, float eps, void* y, long ldy, vtx_rowmap ymap,
+                          float* mean, float* rstd, void* stream);
+/* dx[xmap(m)] = (dres ? dres[xmap(m)] : 0) + LN'(dy[m]);  dgamma/dbeta += column sums.  dtype VTX_BF16_X32: x is float32.
  * workspace: vtx_layernorm_bwd_workspace(rows, D) bytes. */
 size_t vtx_layernorm_bwd_workspace(int rows, int D);
 int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, vtx_rowmap dymap,
@@ -211,7 +223,7 @@ typedef struct {
 int vtx_attn_bwd(const vtx_attn_bwd_desc* d, void* stream);
 
 /* ------------------------------------------------- divided-attention glue ops */
-/* out[b,0,:] = x[b,0,:] + mean_t a_cls[b*T+t,:]   (transformer.py:371-377) */
+/* out[b,0,:] = x[b,0,:] + mean_t a_cls[b*T+t,:]   (transformer.py:371-377); x == NULL: the mean alone (exact residual stream) */
 int vtx_cls_mean_fwd(int dtype, int B, int T, int D, const void* a_cls, long lda,
                      const void* x, void* out, long ld_tok, long rows_per_clip, void* stream);
 /* ViViT fact_encoder glue (video_transformer.py:511-525): x [(B T), 1 + P, D] -> h [B, 1 + T, D],
@@ -232,7 +244,7 @@ int vtx_row_scale_copy(int dtype, int rows, int D, const void* src, long lds, vt
                        void* dst, long ldd, vtx_rowmap dmap, const float* s,
                        int rs_d1, int rs_m1, int rs_d2, int rs_m2, void* stream);
 /* Rows of dropped DropPath groups (s[m / group_rows] == 0.0f; a group = group_rows consecutive rows m of [0, M)):
- *   out[omap(m)] = x[xmap(m)] + bias   (out may be NULL),   zero[m] = 0   (zero may be NULL; compact [M, D] rows).
+ *   out[omap(m)] = x[xmap(m)] + bias   (out may be NULL; x == NULL: the bias alone -- exact residual stream),   zero[m] = 0   (zero may be NULL; compact [M, D] rows).
  * Fix-up behind the merged attn.proj + temporal_fc GEMM: the reference's DropPath sits between the two Linear layers
  * (transformer.py:268-275), so a dropped sequence leaves the block as x + temporal_fc.bias. */
 int vtx_dropped_rows_fix(int dtype, long M, int D, int group_rows, const float* s, const void* x, long ldx,

@@ -115,7 +115,7 @@ int hog_selftest(int* bad_mag, int* bad_bin);     // hog.hip
 
 using namespace vtx;
 
-extern "C" int vtx_version(void) { return 210; }  // 0.2.1: vtx_hog_fwd takes the size of the table blob
+extern "C" int vtx_version(void) { return 220; }  // 0.2.2: vtx_layernorm_acc_fwd / VTX_BF16_X32 (exact residual stream); 0.2.1: vtx_hog_fwd takes the size of the table blob
 
 extern "C" int vtx_set_option(const char* name, const char* value) {
   const int rc = set_option(options(), name, value);

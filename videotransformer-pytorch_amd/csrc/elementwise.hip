@@ -118,8 +118,8 @@ __global__ void cls_mean_fwd_kernel(int B, int T_, int D, const T* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] += v[j];
   }
-  float xv[8];
-  load8(x + (long)b * rows_per_clip * ld + c, xv);
+  float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (x != nullptr) load8(x + (long)b * rows_per_clip * ld + c, xv);     // x == nullptr: the contribution alone (exact residual stream)
   const float inv = 1.0f / (float)T_;
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = xv[j] + acc[j] * inv;
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256) void dropped_rows_fix_kernel(long M, int D, in
     const long m = m0 + r;
     for (int c = lane * 8; c < D; c += 512) {
       if (out) {
-        float v[8], b[8];
-        load8(x + map_row(xmap, m) * ldx + c, v);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8];
+        if (x != nullptr) load8(x + map_row(xmap, m) * ldx + c, v);      // x == nullptr: the row's value is the bias alone
         load8(bias + c, b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += b[j];
@@ -569,7 +569,7 @@ extern "C" int vtx_cast_to_f32(int dtype, size_t n, const void* src, float* dst,
 
 extern "C" int vtx_cls_mean_fwd(int dtype, int B, int T, int D, const void* a_cls, long lda, const void* x, void* out,
                                 long ld_tok, long rows_per_clip, void* stream) {
-  VTX_REQUIRE(B > 0 && T > 0 && D > 0 && D % 8 == 0 && a_cls && x && out, VTX_EINVAL, "cls_mean_fwd: bad arguments");
+  VTX_REQUIRE(B > 0 && T > 0 && D > 0 && D % 8 == 0 && a_cls && out, VTX_EINVAL, "cls_mean_fwd: bad arguments");
   dim3 grid(cdiv((long)B * D / 8, 256)), block(256);
   hipStream_t st = as_stream(stream);
   DISPATCH_T(dtype,
@@ -656,7 +656,7 @@ extern "C" int vtx_dropped_rows_fix(int dtype, long M, int D, int group_rows, co
                                     long ldz, void* stream) {
   VTX_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && group_rows > 0 && s, VTX_EINVAL, "dropped_rows_fix: bad arguments");
   VTX_REQUIRE(out || zero, VTX_EINVAL, "dropped_rows_fix: nothing to do");
-  VTX_REQUIRE(!out || (x && bias), VTX_EINVAL, "dropped_rows_fix: out needs x and bias");
+  VTX_REQUIRE(!out || bias, VTX_EINVAL, "dropped_rows_fix: out needs the bias");
   const long groups = (M + group_rows - 1) / group_rows;
   dim3 grid((unsigned)((groups + 3) / 4)), block(256);
   hipStream_t st = as_stream(stream);

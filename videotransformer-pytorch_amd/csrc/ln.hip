@@ -220,6 +220,117 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd2_kernel(
   }
 }
 
+// ---- the exact residual stream (round 6) ------------------------------------------------------------------------------
+// The bf16 path stores the residual stream as bf16: every sub-block's `x + f(x)` is rounded, 36 (TimeSformer-B) to 72
+// (TimeSformer-L) roundings in series, and the error of the SUM grows with sqrt(depth) -- at 24 layers the outputs deviate 3x as
+// much from the fp32 reference as the reference's own autocast run, which keeps the stream in float32
+// (tests/golden/make_golden_r6.py, tools/precision_study_l96.py).  Under vtx.set_stream('fp32') a sub-block hands on its
+// CONTRIBUTION d = f(x) (bf16, the GEMM epilogue's output without the residual) and the stream itself lives in float32, touched
+// by one kernel per sub-block -- this one, which the LayerNorm of the NEXT sub-block would have been anyway:
+//     xo[omap(r)] = xs[smap(r)] + d[smap(r)]            (float32; xs == nullptr: the first sub-block, the stream starts at d)
+//     y[ymap(r)]  = LayerNorm(xo row) * gamma + beta     (T = bf16; statistics of the float32 row)
+// Two rows per trip as in the backward kernel.  Bytes per row: 4 D + 2 D read, 4 D + 2 D written (1.4 GB per 150 528 x 768
+// launch against 0.46 GB for the bf16 LayerNorm, and the residual GEMM epilogues read and write 0.23 GB less each).
+template <int NCH, bool FULL>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_acc_fwd_kernel(
+    int rows, int D, const float* __restrict__ xs, const bf16raw* __restrict__ d, long lds_, vtx_rowmap smap,
+    float* __restrict__ xo, long ldo, vtx_rowmap omap, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    bf16raw* __restrict__ y, long ldy, vtx_rowmap ymap, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long total_waves = (long)gridDim.x * LN_WAVES;
+  const float invD = 1.0f / (float)D;
+  float gm[NCH][4], bt[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = 4 * (lane + 64 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[c][j] = (FULL || col < D) ? gamma[col + j] : 0.f;
+      bt[c][j] = (FULL || col < D) ? beta[col + j] : 0.f;
+    }
+  }
+  const bool has_xs = xs != nullptr;                   // uniform over the launch
+  struct Row { float4 x[NCH]; uint2 d[NCH]; };
+  auto fetch = [&](long r, Row& w) {
+    const long pr = map_row(smap, r);
+    const bf16raw* dr = d + pr * lds_;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) w.d[c] = ld_raw_nt(reinterpret_cast<const uint2*>(dr + col));
+    }
+    if (has_xs) {
+      const float* xr = xs + pr * lds_;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = 4 * (lane + 64 * c);
+        if (FULL || col < D) w.x[c] = ld_raw_nt(reinterpret_cast<const float4*>(xr + col));
+      }
+    }
+  };
+  auto finish = [&](long r, const Row& w) {
+    float v[NCH][4];
+    float s = 0.f;
+    float* xor_ = xo + map_row(omap, r) * ldo;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+        float dv[4];
+        unpack4(w.d[c], dv);
+        if (has_xs) {
+          unpack4(w.x[c], v[c]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[c][j] += dv[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[c][j] = dv[j];
+        }
+        st4<float>(xor_ + col, v[c]);
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+      } else {
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+      }
+    }
+    if (y == nullptr) return;                          // accumulate only (no LayerNorm of these rows)
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float dd = v[c][j] - mu; q += dd * dd; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+    bf16raw* yr = y + map_row(ymap, r) * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = 4 * (lane + 64 * c);
+      if (FULL || col < D) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rstd * gm[c][j] + bt[c][j];
+        st4<bf16raw>(yr + col, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[r] = mu;
+      if (rstd_out) rstd_out[r] = rstd;
+    }
+  };
+  for (long r = (long)blockIdx.x * LN_WAVES + wave; r < rows; r += 2 * total_waves) {
+    Row ra, rb;
+    const bool two = r + total_waves < rows;
+    fetch(r, ra);
+    fetch(two ? r + total_waves : r, rb);
+    finish(r, ra);
+    if (two) finish(r + total_waves, rb);
+  }
+}
+
 // Backward.  Each wave walks rows r = w, w + W, ...; per-lane column partials of
 // dgamma/dbeta stay in registers, are combined across the block's 4 waves in
 // LDS and written to part[block][2][D]; reduce_partials_kernel finishes.
@@ -228,13 +339,16 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd2_kernel(
 // arithmetic): the kernel is bound by bytes in flight per wave, not by arithmetic.
 // FULL: D == 256 NCH (no column predicate); RES: a residual gradient is added.  Both are compile-time so that the row loop
 // is branch free -- with exec-masked loads in it hipcc falls back to vmcnt(0) waits and the prefetch is lost.
-template <typename T, int NCH, bool FULL, bool RES>
-__global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && NCH <= 3) ? 3 : 1) void ln_bwd_kernel(
+// TX: the type x is stored in -- T, or float for the bf16 kernels under the exact residual stream (vtx_layernorm_acc_fwd below keeps
+// the stream in float32; gradients stay T)
+template <typename T, int NCH, bool FULL, bool RES, typename TX = T>
+__global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && sizeof(TX) == 2 && NCH <= 3) ? 3 : 1) void ln_bwd_kernel(
     int rows, int D, const T* __restrict__ dy, long lddy, vtx_rowmap dymap,
-    const T* __restrict__ x, long ldx, vtx_rowmap xmap, const float* __restrict__ mean,
+    const TX* __restrict__ x, long ldx, vtx_rowmap xmap, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ dres,
     T* __restrict__ dx, long lddx, float* __restrict__ part) {
   typedef typename Raw4<T>::type raw_t;
+  typedef typename Raw4<TX>::type rawx_t;
   __shared__ float red[LN_WAVES][2][NCH * 256];
   __shared__ float gsm[NCH * 256];                 // gamma: read per row from LDS instead of held in 4*NCH registers
   const int lane = threadIdx.x & 63;
@@ -248,10 +362,10 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && NCH <= 3) ? 3 : 1
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
-  struct Row { raw_t x[NCH], dy[NCH], dr[NCH]; float mu, rs; long pr; };
+  struct Row { rawx_t x[NCH]; raw_t dy[NCH], dr[NCH]; float mu, rs; long pr; };
   auto fetch = [&](long r, Row& w) {
     w.pr = map_row(xmap, r);
-    const T* xr = x + w.pr * ldx;
+    const TX* xr = x + w.pr * ldx;
     const T* dyr = dy + map_row(dymap, r) * lddy;
     const T* drr = dres + w.pr * lddx;
     w.mu = mean[r]; w.rs = rstd[r];
@@ -259,7 +373,7 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && NCH <= 3) ? 3 : 1
     for (int c = 0; c < NCH; ++c) {
       const int col = 4 * (lane + 64 * c);
       if (FULL || col < D) {
-        w.x[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(xr + col));
+        w.x[c] = ld_raw_nt(reinterpret_cast<const rawx_t*>(xr + col));
         w.dy[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(dyr + col));
         if (RES) w.dr[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(drr + col));
       }
@@ -578,7 +692,7 @@ static int ln_fwd_t(int rows, int D, const void* x, long ldx, vtx_rowmap xmap, c
   return check_launch("layernorm_fwd");
 }
 
-template <typename T>
+template <typename T, typename TX = T>
 static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap, const void* x,
                     long ldx, vtx_rowmap xmap, const float* mean, const float* rstd,
                     const float* gamma, const void* dres, void* dx, long lddx, float* part,
@@ -595,11 +709,11 @@ static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap
 #define LN_BWD_(N, F, R)                                                                           \
   {                                                                                                \
     static int per_cu = 0;                                                                         \
-    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_bwd_kernel<T, N, F, R>, LN_WAVES * 64, 0) \
+    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_bwd_kernel<T, N, F, R, TX>, LN_WAVES * 64, 0) \
                         != hipSuccess || per_cu <= 0)) per_cu = 2;                                 \
     dim3 g(nblocks < per_cu * n_cu ? nblocks : per_cu * n_cu);                                     \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, N, F, R>), g, b, 0, st, rows, D, (const T*)dy, lddy, dymap, \
-                       (const T*)x, ldx, xmap, mean, rstd, gamma, (const T*)dres, (T*)dx, lddx, part); \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, N, F, R, TX>), g, b, 0, st, rows, D, (const T*)dy, lddy, dymap, \
+                       (const TX*)x, ldx, xmap, mean, rstd, gamma, (const T*)dres, (T*)dx, lddx, part); \
     *launched = (int)g.x;                                                                          \
   }
 #define LN_BWD(N)                                                                                  \
@@ -639,6 +753,26 @@ extern "C" int vtx_layernorm_fwd(int dtype, int rows, int D, const void* x, long
   VTX_REQUIRE(false, VTX_EINVAL, "layernorm_fwd: bad dtype %d", dtype);
 }
 
+extern "C" int vtx_layernorm_acc_fwd(int rows, int D, const float* xs, const void* d, long lds, vtx_rowmap smap, float* xo, long ldo,
+                                    vtx_rowmap omap, const float* gamma, const float* beta, float eps, void* y, long ldy,
+                                    vtx_rowmap ymap, float* mean, float* rstd, void* stream) {
+  VTX_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0 && D <= 1024, VTX_EINVAL, "layernorm_acc_fwd: D=%d must be a multiple of 4 and <= 1024", D);
+  if (rows == 0) return VTX_OK;
+  VTX_REQUIRE(d && xo && (y == nullptr || (gamma && beta)), VTX_EINVAL, "layernorm_acc_fwd: null pointer");
+  VTX_REQUIRE(aligned16(d) && aligned16(xo) && (!xs || aligned16(xs)) && (!y || (aligned16(y) && aligned16(gamma) && aligned16(beta))) &&
+                  lds % 4 == 0 && ldo % 4 == 0 && ldy % 4 == 0, VTX_EALIGN, "layernorm_acc_fwd: 16-byte alignment required");
+  if (y == nullptr) { gamma = xo; beta = xo; }       // never applied; the kernel loads its register copies from valid memory
+  const int nch = cdiv(D, 256);
+  dim3 g(ln_blocks((rows + 1) / 2)), b(LN_WAVES * 64);
+  hipStream_t st = as_stream(stream);
+#define LN_ACC(N)                                                                                                         \
+  { if (D == N * 256) hipLaunchKernelGGL((ln_acc_fwd_kernel<N, true>), g, b, 0, st, rows, D, xs, (const bf16raw*)d, lds, smap, xo, ldo, omap, gamma, beta, eps, (bf16raw*)y, ldy, ymap, mean, rstd); \
+    else hipLaunchKernelGGL((ln_acc_fwd_kernel<N, false>), g, b, 0, st, rows, D, xs, (const bf16raw*)d, lds, smap, xo, ldo, omap, gamma, beta, eps, (bf16raw*)y, ldy, ymap, mean, rstd); }
+  if (nch == 1) LN_ACC(1) else if (nch == 2) LN_ACC(2) else if (nch == 3) LN_ACC(3) else LN_ACC(4)
+#undef LN_ACC
+  return check_launch("layernorm_acc_fwd");
+}
+
 extern "C" size_t vtx_layernorm_bwd_workspace(int rows, int D) {
   return (size_t)ln_bwd_blocks(rows) * 2 * (size_t)D * sizeof(float);
 }
@@ -662,6 +796,8 @@ extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, lon
     rc = ln_bwd_t<float>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, &launched, st);
   else if (dtype == VTX_BF16)
     rc = ln_bwd_t<bf16raw>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, &launched, st);
+  else if (dtype == VTX_BF16_X32)                    // gradients bf16, x float32 (the exact residual stream)
+    rc = ln_bwd_t<bf16raw, float>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, dres, dx, lddx, part, nb, &launched, st);
   else
     VTX_REQUIRE(false, VTX_EINVAL, "layernorm_bwd: bad dtype %d", dtype);
   if (rc) return rc;

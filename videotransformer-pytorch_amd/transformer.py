@@ -94,6 +94,28 @@ class DropPath(nn.Module):
         return F_.RowScaleFn.apply(x, s, rows_per)
 
 
+def _stream_of(t):
+    """(float32 stream, exact?) for a block input under vtx.set_stream('fp32'): the stream rides on the contribution tensor as an
+    attribute (it is a side buffer, not an autograd tensor -- vtx/functions.py, "the exact residual stream").  Exact mode is the
+    bf16 path only; float32 activations are their own exact stream."""
+    exact = F_.exact_stream() and t.dtype == torch.bfloat16
+    return (getattr(t, '_vtx_xs', None) if exact else None), exact
+
+
+def _with_stream(res, exact):
+    """What a block hands on: the contribution with the new float32 stream attached (exact), or the bf16 stream itself."""
+    if not exact:
+        return res
+    out, x32 = res
+    out._vtx_xs = x32
+    return out
+
+
+def _no_exact(what):
+    if F_.exact_stream() and vtx.compute_dtype() == torch.bfloat16:
+        raise NotImplementedError(f"vtx.set_stream('fp32') covers the divided space-time blocks only, not {what}")
+
+
 def _drop_scale(layer_drop, rows, ndim, device):
     return layer_drop.scale_vector(rows, ndim, device) if isinstance(layer_drop, DropPath) else None
 
@@ -234,22 +256,24 @@ class DividedTemporalAttentionWithPreNorm(_DividedBase):
                                       'dead branch of the reference models and is not implemented')
         self._guard()
         x = _to_compute(query)
+        xs, exact = _stream_of(query)
         b, n1, d = x.shape
         t = self.num_frames
         if (n1 - 1) % t:
             raise ValueError(f'{n1 - 1} tokens per clip are not a multiple of num_frames={t}')
         p = (n1 - 1) // t
         if return_attention:
+            _no_exact('the attention map of a temporal block')
             tok = x[:, 1:].reshape(b * p, t, d)
             out = F_.SelfAttnFn.apply(tok, self.norm.weight, self.norm.bias, self.attn.qkv.weight,
                                       self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias,
                                       self.num_heads, None, True, self.norm.eps)
             return out
         s = _drop_scale(self.layer_drop, b * p, 3, x.device)
-        return F_.TimeAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
-                        self.attn.proj.weight, self.attn.proj.bias, self.temporal_fc.weight,
-                        self.temporal_fc.bias, t, self.num_heads, s, self.norm.eps,
-                        _keep_scale(self.layer_drop) if s is not None else None)
+        return _with_stream(F_.TimeAttnFn.apply(
+            x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias, self.attn.proj.weight,
+            self.attn.proj.bias, self.temporal_fc.weight, self.temporal_fc.bias, t, self.num_heads, s, self.norm.eps,
+            _keep_scale(self.layer_drop) if s is not None else None, xs, exact), exact)
 
 
 class DividedSpatialAttentionWithPreNorm(_DividedBase):
@@ -271,14 +295,16 @@ class DividedSpatialAttentionWithPreNorm(_DividedBase):
                                       'dead branch of the reference models and is not implemented')
         self._guard()
         x = _to_compute(query)
+        xs, exact = _stream_of(query)
         b = x.shape[0]
         t = self.num_frames
         if (x.shape[1] - 1) % t:
             raise ValueError(f'{x.shape[1] - 1} tokens per clip are not a multiple of num_frames={t}')
         s = None if return_attention else _drop_scale(self.layer_drop, b * t, 3, x.device)
-        return F_.SpaceAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
-                                    self.attn.proj.weight, self.attn.proj.bias, t, self.num_heads, s,
-                                    bool(return_attention), self.norm.eps)
+        res = F_.SpaceAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+                                   self.attn.proj.weight, self.attn.proj.bias, t, self.num_heads, s,
+                                   bool(return_attention), self.norm.eps, xs, exact)
+        return res if return_attention else _with_stream(res, exact)
 
 
 class MultiheadAttentionWithPreNorm(nn.Module):
@@ -299,6 +325,7 @@ class MultiheadAttentionWithPreNorm(nn.Module):
         if self.training:
             _no_dropout(self.proj_drop.p, 'proj_drop')
             _no_dropout(self.attn.attn_drop.p, 'attn_drop')
+        _no_exact('MultiheadAttentionWithPreNorm (space_only / joint_space_time / ViViT encoders)')
         x = _to_compute(query)
         s = None if return_attention else _drop_scale(self.layer_drop, x.shape[0], 3, x.device)
         return F_.SelfAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
@@ -333,11 +360,12 @@ class FFNWithPreNorm(nn.Module):
     def forward(self, x):
         if self.training:
             _no_dropout(self.dropout_p, 'dropout_p')
+        xs, exact = _stream_of(x)
         x = _to_compute(x)
         s = _drop_scale(self.layer_drop, x.shape[0], x.ndim, x.device)
         fc1, fc2 = self.layers[0][0], self.layers[1]
-        return F_.FFNFn.apply(x, self.norm.weight, self.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, s,
-                              self.norm.eps)
+        return _with_stream(F_.FFNFn.apply(x, self.norm.weight, self.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, s,
+                                           self.norm.eps, xs, exact), exact)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -404,6 +432,7 @@ class TransformerContainer(nn.Module):
             if return_attention and idx >= last:
                 x = layer(x, return_attention=True)
             elif recompute:
+                _no_exact('vtx.set_recompute(True)')
                 # the CPU generator state is saved and restored around the re-run: DropPath draws the same masks
                 x = torch.utils.checkpoint.checkpoint(layer, x, use_reentrant=False)
             else:

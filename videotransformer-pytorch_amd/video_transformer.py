@@ -59,10 +59,13 @@ class _VideoTransformerBase(nn.Module):
                                  vtx.compute_dtype(), layout)
 
     def _readout(self, x):
+        # under vtx.set_stream('fp32') x is the last sub-block's contribution and carries the float32 stream (transformer._stream_of)
+        exact = F_.exact_stream() and x.dtype == torch.bfloat16 and getattr(x, '_vtx_xs', None) is not None
+        xs = x._vtx_xs if exact else None
         if self.return_cls_token:
-            y = F_.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, True)
+            y = F_.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, True, xs, exact)
             return F_.CastFn.apply(y, torch.float32)
-        y = F_.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, False)
+        y = F_.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, False, xs, exact)
         return F_.CastFn.apply(y, torch.float32)[:, 1:].mean(1)
 
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get('VTX_LIB', os.path.join(_PKG, 'libvtx.so'))
 
-VTX_F32, VTX_BF16 = 0, 1
+VTX_F32, VTX_BF16, VTX_BF16_X32 = 0, 1, 3
 ATTN_CONTIG, ATTN_SPACE = 0, 1
 
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     'vtx_last_error_string': (C.c_char_p, []),
     'vtx_set_option': (ci, [C.c_char_p, C.c_char_p]),
     'vtx_layernorm_fwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, vp, cf, vp, cl, RowMap, vp, vp, vp]),
+    'vtx_layernorm_acc_fwd': (ci, [ci, ci, vp, vp, cl, RowMap, vp, cl, RowMap, vp, vp, cf, vp, cl, RowMap, vp, vp, vp]),
     'vtx_layernorm_bwd_workspace': (sz, [ci, ci]),
     'vtx_layernorm_bwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, vp, vp, vp, vp, cl,
                                vp, vp, vp, sz, vp]),

@@ -197,6 +197,35 @@ def _ln_grad_buffers(ln_w, ln_b, D, device):
     return (torch.zeros(D, dtype=torch.float32, device=device), torch.zeros(D, dtype=torch.float32, device=device), False)
 
 
+# ---- the exact residual stream -------------------------------------------------------------------------
+# vtx.set_stream('fp32'): a sub-block returns its CONTRIBUTION d = f(x) (bf16) next to the float32 stream it read, and the next
+# sub-block's LayerNorm kernel forms x = xs + d in float32 (vtx_layernorm_acc_fwd) -- no bf16 rounding of the running sum.  The
+# float32 stream is a side buffer, not an autograd tensor: gradients flow through the chain of contributions exactly as they
+# flow through the bf16 stream (d(xs + d)/dd = 1), so every backward below is shared between the two modes.  TimeSformer /
+# ViViT divided_space_time blocks only (the other attention types raise).
+_exact = False
+
+
+def set_exact_stream(on):
+    global _exact
+    _exact = bool(on)
+
+
+def exact_stream():
+    return _exact
+
+
+_zero1 = {}
+
+
+def _zero_rows(finite_src, dst, rows, D, rowmap):
+    """dst[rowmap(m)] = 0 for m < rows (0 * finite_src[rowmap(m)]: the source only has to be finite)."""
+    z = _zero1.get(dst.device)
+    if z is None:
+        z = _zero1[dst.device] = torch.zeros(1, dtype=torch.float32, device=dst.device)
+    ops.row_scale_copy(finite_src, dst, rows, D, smap=rowmap, dmap=rowmap, s=z, rs=(1, 0, 1, 0))
+
+
 def _empty(shape, like, dtype=None):
     return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
 
@@ -225,7 +254,9 @@ class TimeAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b, T, heads, scale_vec, eps=1e-5,
-                keep_scale=None):
+                keep_scale=None, xs=None, exact=False):
+        # exact: x is the previous sub-block's contribution d, xs the float32 stream it was computed from (None: the stream
+        # starts at d); returns (this block's contribution, the float32 stream xs + d)
         x = _chk(x)
         B, N1, D = x.shape
         N = N1 - 1
@@ -238,7 +269,14 @@ class TimeAttnFn(torch.autograd.Function):
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        x32 = None
+        if exact:
+            x32 = torch.empty(B, N1, D, dtype=torch.float32, device=x.device)
+            ops.layernorm_acc_fwd(xs, x, M, D, D, tm, x32, D, tm, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+            ops.layernorm_acc_fwd(xs, x, B, D, D, ops.clsmap(N), x32, D, ops.clsmap(N))       # the cls rows: accumulate only
+        else:
+            ops.layernorm_fwd(x, M, D, D, tm, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        res = None if exact else x                  # the residual the GEMM epilogue adds: none under the exact stream
         wq, wqT = weights(qkv_w, dtp, need_t)
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
@@ -251,9 +289,9 @@ class TimeAttnFn(torch.autograd.Function):
         if merged:
             c = 1.0 if scale_vec is None else float(keep_scale)
             wc, wcT, bias = merged_proj(proj_w, proj_b, tfc_w, tfc_b, dtp, need_t, c)
-            ops.gemm_nt(o, wc, out, M, D, D, cmap=tm, bias=bias, R=x, rmap=tm, row_scale=scale_vec, rs=(T, 1, 1, 0))
+            ops.gemm_nt(o, wc, out, M, D, D, cmap=tm, bias=bias, R=res, rmap=tm, row_scale=scale_vec, rs=(T, 1, 1, 0))
             if scale_vec is not None:
-                ops.dropped_rows_fix(scale_vec, M, D, T, x=x, xmap=tm, bias=tfc_b.detach(), out=out, omap=tm, zero=o)
+                ops.dropped_rows_fix(scale_vec, M, D, T, x=res, xmap=tm, bias=tfc_b.detach(), out=out, omap=tm, zero=o)
             a = x.new_empty(0)
             wts = [t for t in (wqT, wcT) if t is not None]
         else:
@@ -261,17 +299,24 @@ class TimeAttnFn(torch.autograd.Function):
             a = _empty((M, D), x)
             ops.gemm_nt(o, wp, a, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(T, 1, 1, 0))
             wt, wtT = weights(tfc_w, dtp, need_t)
-            ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=x, rmap=tm)
+            ops.gemm_nt(a, wt, out, M, D, D, cmap=tm, bias=tfc_b, R=res, rmap=tm)
             wts = [t for t in (wqT, wpT, wtT) if t is not None]
-        ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse, a,
+        if exact:
+            _zero_rows(x, out, B, D, ops.clsmap(N))                 # the block contributes nothing to the cls rows
+        else:
+            ops.row_scale_copy(x, out, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
+        ctx.save_for_backward(x32 if exact else x, ln_w, mean, rstd, xn, qkv, o, lse, a,
                               scale_vec if scale_vec is not None else x.new_empty(0), *wts)
         ctx.cfg = (T, heads, scale_vec is not None, merged, keep_scale)
         ctx.params = (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, tfc_w, tfc_b)
+        if exact:
+            ctx.mark_non_differentiable(x32)
+            return out, x32
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstream=None):
+        # (x: the saved stream -- bf16, or float32 under the exact stream; every buffer below takes its dtype from dout)
         x, ln_w, mean, rstd, xn, qkv, o, lse, a, sv, wqT, *wrest = ctx.saved_tensors
         p_ln_w, p_ln_b, p_qkv_w, p_qkv_b, p_proj_w, p_proj_b, p_tfc_w, p_tfc_b = ctx.params
         T, heads, has_scale, merged, keep_scale = ctx.cfg
@@ -283,7 +328,8 @@ class TimeAttnFn(torch.autograd.Function):
         hd = D // heads
         S = M // T
         tm = ops.tokmap(N)
-        dtp = x.dtype
+        dtp = dout.dtype
+        x_stream, x = x, dout                          # allocation template from here on
         do = _empty((M, D), x)
         if merged:
             wcT, = wrest
@@ -329,12 +375,12 @@ class TimeAttnFn(torch.autograd.Function):
         # LayerNorm + residual
         dx = torch.empty_like(x)
         d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
         if direct:
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
         ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None, None)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------
@@ -345,8 +391,8 @@ class SpaceAttnFn(torch.autograd.Function):
     clip instead of once per frame); only the attention kernel regroups rows."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, T, heads, scale_vec, want_probs, eps=1e-5):
-        x = _chk(x)
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, T, heads, scale_vec, want_probs, eps=1e-5, xs=None, exact=False):
+        x = _chk(x)                                  # exact: the contribution d of the previous sub-block (see TimeAttnFn)
         B, N1, D = x.shape
         N = N1 - 1
         P = N // T
@@ -356,7 +402,12 @@ class SpaceAttnFn(torch.autograd.Function):
         xn = _empty((M1, D), x)
         mean = _empty((M1,), x, torch.float32)
         rstd = _empty((M1,), x, torch.float32)
-        ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        x32 = None
+        if exact:
+            x32 = torch.empty(B, N1, D, dtype=torch.float32, device=x.device)
+            ops.layernorm_acc_fwd(xs, x, M1, D, D, IDENT, x32, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        else:
+            ops.layernorm_fwd(x, M1, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M1, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M1, 3 * D, D, bias=qkv_b)
@@ -374,17 +425,20 @@ class SpaceAttnFn(torch.autograd.Function):
         a_cls = _empty((B * T, D), x)
         tm = ops.tokmap(N)
         ops.gemm_nt(o, wp, out, Mo, D, D, cmap=tm, bias=proj_b, row_scale=scale_vec, rs=(N, T, T, 1),
-                    R=x, rmap=tm, split_row=B * N, Csplit=a_cls)
-        ops.cls_mean_fwd(a_cls, x, out, B, T, D, N1)
-        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse,
+                    R=None if exact else x, rmap=tm, split_row=B * N, Csplit=a_cls)
+        ops.cls_mean_fwd(a_cls, None if exact else x, out, B, T, D, N1)
+        ctx.save_for_backward(x32 if exact else x, ln_w, mean, rstd, xn, qkv, o, lse,
                               scale_vec if scale_vec is not None else x.new_empty(0),
                               *[t for t in (wqT, wpT) if t is not None])
         ctx.cfg = (T, heads, scale_vec is not None)
         ctx.params = (ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b)
+        if exact:
+            ctx.mark_non_differentiable(x32)
+            return out, x32
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstream=None):
         x, ln_w, mean, rstd, xn, qkv, o, lse, sv, wqT, wpT = ctx.saved_tensors
         p_ln_w, p_ln_b, p_qkv_w, p_qkv_b, p_proj_w, p_proj_b = ctx.params
         T, heads, has_scale = ctx.cfg
@@ -396,7 +450,8 @@ class SpaceAttnFn(torch.autograd.Function):
         M1 = B * N1
         Mo = B * N + B * T
         hd = D // heads
-        dtp = x.dtype
+        dtp = dout.dtype
+        x_stream, x = x, dout                          # (the saved stream may be float32: buffers take dout's dtype)
         da = _empty((Mo, D), x)
         ops.space_grad_prep(dout, sv, da, B, T, P, D)
         d_proj_w, d_proj_b = _linear_grads(p_proj_w, p_proj_b, da, o, Mo, D, D)
@@ -412,11 +467,11 @@ class SpaceAttnFn(torch.autograd.Function):
         ops.gemm_nt(dqkv, wqT, dxn, M1, D, 3 * D)
         dx = torch.empty_like(x)
         d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M1, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, IDENT, M1, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
         if direct:
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None, None, None)
 
 
 class SelfAttnFn(torch.autograd.Function):
@@ -536,8 +591,8 @@ class FFNFn(torch.autograd.Function):
     """FFNWithPreNorm.forward with num_layers == 2 (reference transformer.py:516-523)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale_vec, eps=1e-5):
-        x = _chk(x)
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale_vec, eps=1e-5, xs=None, exact=False):
+        x = _chk(x)                                  # exact: the contribution d of the previous sub-block (see TimeAttnFn)
         D = x.shape[-1]
         M = x.numel() // D
         rows_per = M // x.shape[0]
@@ -545,11 +600,16 @@ class FFNFn(torch.autograd.Function):
         dtp = x.dtype
         plan = _compaction_plan(scale_vec, x.shape[0], rows_per, x.device)
         if plan is not None:
-            return FFNFn._forward_compact(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, plan, rows_per)
+            return FFNFn._forward_compact(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, plan, rows_per, xs, exact)
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        x32 = None
+        if exact:
+            x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            ops.layernorm_acc_fwd(xs, x, M, D, D, IDENT, x32, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        else:
+            ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         w1c, w1T = weights(w1, dtp, any(ctx.needs_input_grad))
         # the second output is gelu'(pre-activation), not the pre-activation: it is all the backward needs of it
         # (transformer.py:503 nn.GELU), computed from the same erf / exp evaluation, and the backward's epilogue
@@ -559,16 +619,19 @@ class FFNFn(torch.autograd.Function):
         ops.gemm_nt(xn, w1c, g, M, Hd, D, bias=b1, act=2, C2=h)
         w2c, w2T = weights(w2, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
-        ops.gemm_nt(g, w2c, out, M, D, Hd, bias=b2, row_scale=scale_vec, rs=(rows_per, 1, 1, 0), R=x)
-        ctx.save_for_backward(x, ln_w, mean, rstd, xn, h, g,
+        ops.gemm_nt(g, w2c, out, M, D, Hd, bias=b2, row_scale=scale_vec, rs=(rows_per, 1, 1, 0), R=None if exact else x)
+        ctx.save_for_backward(x32 if exact else x, ln_w, mean, rstd, xn, h, g,
                               scale_vec if scale_vec is not None else x.new_empty(0),
                               *[t for t in (w1T, w2T) if t is not None])
         ctx.cfg = (rows_per, scale_vec is not None, w1.shape[0])
         ctx.params = (ln_w, ln_b, w1, b1, w2, b2)
+        if exact:
+            ctx.mark_non_differentiable(x32)
+            return out, x32
         return out
 
     @staticmethod
-    def _forward_compact(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, plan, rows_per):
+    def _forward_compact(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, plan, rows_per, xs=None, exact=False):
         """The kept clips only (see _compaction_plan); the dropped clips leave the block as they came in."""
         nk, nd, step_k, step_d, buf = plan
         kmap, dmap, sv_k = _plan_maps(plan, rows_per)
@@ -580,22 +643,34 @@ class FFNFn(torch.autograd.Function):
         need_t = any(ctx.needs_input_grad)
         w1c, w1T = weights(w1, dtp, need_t)
         w2c, w2T = weights(w2, dtp, need_t)
+        x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if exact else None
         if nk > 0:
             xn = _empty((Mk, D), x)
             mean = _empty((Mk,), x, torch.float32)
             rstd = _empty((Mk,), x, torch.float32)
-            ops.layernorm_fwd(x, Mk, D, D, kmap, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+            if exact:
+                ops.layernorm_acc_fwd(xs, x, Mk, D, D, kmap, x32, D, kmap, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+            else:
+                ops.layernorm_fwd(x, Mk, D, D, kmap, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
             h = _empty((Mk, Hd), x)
             g = _empty((Mk, Hd), x)
             ops.gemm_nt(xn, w1c, g, Mk, Hd, D, bias=b1, act=2, C2=h)
-            ops.gemm_nt(g, w2c, out, Mk, D, Hd, cmap=kmap, bias=b2, row_scale=sv_k, rs=(rows_per, 1, 1, 0), R=x, rmap=kmap)
+            ops.gemm_nt(g, w2c, out, Mk, D, Hd, cmap=kmap, bias=b2, row_scale=sv_k, rs=(rows_per, 1, 1, 0),
+                        R=None if exact else x, rmap=kmap)
         else:
             xn = mean = rstd = h = g = x.new_empty(0)
-        ops.row_scale_copy(x, out, nd * rows_per, D, smap=dmap, dmap=dmap)
-        ctx.save_for_backward(x, ln_w, mean, rstd, xn, h, g, buf, *[t for t in (w1T, w2T) if t is not None])
+        if exact:                                    # the dropped clips: the stream moves on, the block contributes nothing
+            ops.layernorm_acc_fwd(xs, x, nd * rows_per, D, D, dmap, x32, D, dmap)
+            _zero_rows(x, out, nd * rows_per, D, dmap)
+        else:
+            ops.row_scale_copy(x, out, nd * rows_per, D, smap=dmap, dmap=dmap)
+        ctx.save_for_backward(x32 if exact else x, ln_w, mean, rstd, xn, h, g, buf, *[t for t in (w1T, w2T) if t is not None])
         ctx.cfg = (rows_per, True, Hd)
         ctx.plan = (nk, nd, step_k, step_d)
         ctx.params = (ln_w, ln_b, w1, b1, w2, b2)
+        if exact:
+            ctx.mark_non_differentiable(x32)
+            return out, x32
         return out
 
     @staticmethod
@@ -608,6 +683,7 @@ class FFNFn(torch.autograd.Function):
         dout = _chk(dout)
         D = x.shape[-1]
         Mk = nk * rows_per
+        x_stream, x = x, dout                          # (the saved stream may be float32: buffers take dout's dtype)
         dx = torch.empty_like(x)
         d_ln_w = d_ln_b = d_w1 = d_b1 = d_w2 = d_b2 = None
         if nk > 0:
@@ -620,7 +696,7 @@ class FFNFn(torch.autograd.Function):
             dxn = _empty((Mk, D), x)
             ops.gemm_nt(dh, w1T, dxn, Mk, D, Hd)
             d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-            ops.layernorm_bwd(dxn, D, IDENT, x, D, kmap, Mk, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+            ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, kmap, Mk, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
             if direct:
                 _fire(p_ln_w, p_ln_b)
                 d_ln_w = d_ln_b = None
@@ -631,10 +707,10 @@ class FFNFn(torch.autograd.Function):
             zeros = [None if _sink(p) is not None else torch.zeros_like(p) for p in (p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2)]
             d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2 = zeros
         ops.row_scale_copy(dout, dx, nd * rows_per, D, smap=dmap, dmap=dmap)
-        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None)
+        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None, None, None)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstream=None):
         if getattr(ctx, 'plan', None) is not None:
             return FFNFn._backward_compact(ctx, dout)
         x, ln_w, mean, rstd, xn, h, g, sv, w1T, w2T = ctx.saved_tensors
@@ -643,7 +719,8 @@ class FFNFn(torch.autograd.Function):
         dout = _chk(dout)
         D = x.shape[-1]
         M = x.numel() // D
-        dtp = x.dtype
+        dtp = dout.dtype
+        x_stream, x = x, dout                          # (the saved stream may be float32: buffers take dout's dtype)
         if has_scale:
             dz = _empty((M, D), x)
             ops.row_scale_copy(dout, dz, M, D, s=sv, rs=(rows_per, 1, 1, 0))
@@ -657,11 +734,11 @@ class FFNFn(torch.autograd.Function):
         ops.gemm_nt(dh, w1T, dxn, M, D, Hd)
         dx = torch.empty_like(x)
         d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
         if direct:
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
-        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None)
+        return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None, None, None)
 
 
 class TokensFn(torch.autograd.Function):
@@ -775,10 +852,11 @@ class PatchEmbedFn(torch.autograd.Function):
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim of x [.., D]; ``cls_only`` normalises only row 0
     of every [1+N, D] sequence and returns [B, D] (final norm + x[:, 0],
-    reference video_transformer.py:251-254 / :527-530)."""
+    reference video_transformer.py:251-254 / :527-530).  exact (the exact residual stream, see TimeAttnFn): x is the last
+    sub-block's contribution, xs the float32 stream it was computed from; the rows are normalised as xs + x."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, cls_only):
+    def forward(ctx, x, w, b, eps, cls_only, xs=None, exact=False):
         x = _chk(x)
         D = x.shape[-1]
         if cls_only:
@@ -790,23 +868,38 @@ class LayerNormFn(torch.autograd.Function):
             y = torch.empty_like(x)
         mean = _empty((rows,), x, torch.float32)
         rstd = _empty((rows,), x, torch.float32)
-        ops.layernorm_fwd(x, rows, D, D, xmap, w, b, eps, y, D, IDENT, mean, rstd)
-        ctx.save_for_backward(x, w, mean, rstd)
-        ctx.cfg = (rows, cls_only)
+        if exact:
+            x32 = torch.empty(rows, D, dtype=torch.float32, device=x.device)      # the normalised rows of the stream, compact
+            ops.layernorm_acc_fwd(xs, x, rows, D, D, xmap, x32, D, IDENT, w, b, eps, y, D, IDENT, mean, rstd)
+            ctx.save_for_backward(x32, w, mean, rstd)
+        else:
+            ops.layernorm_fwd(x, rows, D, D, xmap, w, b, eps, y, D, IDENT, mean, rstd)
+            ctx.save_for_backward(x, w, mean, rstd)
+        ctx.cfg = (rows, cls_only, exact, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
-        rows, cls_only = ctx.cfg
+        rows, cls_only, exact, shape = ctx.cfg
         dy = _chk(dy)
         D = x.shape[-1]
-        xmap = ops.clsmap(x.shape[1] - 1) if cls_only else IDENT
-        dx = torch.zeros_like(x) if cls_only else torch.empty_like(x)
         d_w = torch.zeros(D, dtype=torch.float32, device=x.device)
         d_b = torch.zeros(D, dtype=torch.float32, device=x.device)
+        if exact:
+            # x: the compact float32 rows; their gradient goes back to the rows' places in the stream layout
+            dxc = torch.empty(rows, D, dtype=dy.dtype, device=dy.device)
+            ops.layernorm_bwd(dy, D, IDENT, x, D, IDENT, rows, D, mean, rstd, w, None, dxc, D, d_w, d_b)
+            if cls_only:
+                dx = torch.zeros(shape, dtype=dy.dtype, device=dy.device)
+                ops.row_scale_copy(dxc, dx, rows, D, smap=IDENT, dmap=ops.clsmap(shape[1] - 1))
+            else:
+                dx = dxc.view(shape)
+            return dx, d_w, d_b, None, None, None, None
+        xmap = ops.clsmap(x.shape[1] - 1) if cls_only else IDENT
+        dx = torch.zeros_like(x) if cls_only else torch.empty_like(x)
         ops.layernorm_bwd(dy, D, IDENT, x, D, xmap, rows, D, mean, rstd, w, None, dx, D, d_w, d_b)
-        return dx, d_w, d_b, None, None
+        return dx, d_w, d_b, None, None, None, None
 
 
 def _pad8(n):

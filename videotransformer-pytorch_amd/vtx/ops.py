@@ -138,12 +138,27 @@ def layernorm_fwd(x, rows, D, ldx, xmap, gamma, beta, eps, y, ldy, ymap=IDENT, m
              ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
 
 
+def layernorm_acc_fwd(xs, d, rows, D, lds, smap, xo, ldo, omap, gamma=None, beta=None, eps=1e-5, y=None, ldy=0, ymap=IDENT,
+                      mean=None, rstd=None):
+    """The exact residual stream (vtx_layernorm_acc_fwd): xo = (xs or 0) + d in float32 on the mapped rows and, with ``y``, the
+    LayerNorm of those rows (bf16).  xs: float32 stream or None; d: bf16 contribution in the stream layout."""
+    need_cuda(d, xo, xs, y)
+    if d.dtype != torch.bfloat16 or xo.dtype != torch.float32 or (xs is not None and xs.dtype != torch.float32):
+        raise TypeError('layernorm_acc_fwd: d bfloat16, xs / xo float32')
+    nb = rows * D * (2 + 4 + (4 if xs is not None else 0) + (2 if y is not None else 0))
+    with _timed('ln_fwd', nbytes=nb, key=f'acc {rows}x{D}'):
+        call('vtx_layernorm_acc_fwd', rows, D, ptr(xs), ptr(d), lds, smap, ptr(xo), ldo, omap, ptr(_f32(gamma)), ptr(_f32(beta)),
+             float(eps), ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
+
+
 def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dres, dx, lddx, dgamma, dbeta):
     need_cuda(dy, x, dx)
     ws_bytes = _lib.load().vtx_layernorm_bwd_workspace(rows, D)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-    with _timed('ln_bwd', nbytes=(4.0 if dres is not None else 3.0) * rows * D * x.element_size(), key=f'{rows}x{D}'):
-        call('vtx_layernorm_bwd', dt(x), rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd),
+    # bf16 gradients with x stored as float32: the exact residual stream (vtx.set_stream('fp32'))
+    mixed = dy.dtype == torch.bfloat16 and x.dtype == torch.float32
+    with _timed('ln_bwd', nbytes=((3.0 if dres is not None else 2.0) * dy.element_size() + x.element_size()) * rows * D, key=f'{rows}x{D}'):
+        call('vtx_layernorm_bwd', _lib.VTX_BF16_X32 if mixed else dt(dy), rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd),
              ptr(gamma), ptr(dres), ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, stream())
 
 
@@ -341,7 +356,7 @@ def fact_glue_bwd(dh, B, T, P, D, d_time_embed=None, accumulate=False):
 
 
 def cls_mean_fwd(a_cls, x, out, B, T, D, rows_per_clip):
-    call('vtx_cls_mean_fwd', dt(x), B, T, D, ptr(a_cls), D, ptr(x), ptr(out), D, rows_per_clip, stream())
+    call('vtx_cls_mean_fwd', dt(out), B, T, D, ptr(a_cls), D, ptr(x), ptr(out), D, rows_per_clip, stream())     # x None: the mean alone
 
 
 def space_grad_prep(dout, s, da, B, T, P, D):
