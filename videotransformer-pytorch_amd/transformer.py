@@ -111,9 +111,18 @@ def _with_stream(res, exact):
     return out
 
 
+def stream_value(t):
+    """The stream as one tensor for consumers outside the blocks: t itself, or bf16(float32 stream + contribution) under the
+    exact stream (vtx.functions.StreamValueFn)."""
+    xs, exact = _stream_of(t)
+    if not exact or xs is None:
+        return t
+    return F_.StreamValueFn.apply(t, xs)
+
+
 def _no_exact(what):
     if F_.exact_stream() and vtx.compute_dtype() == torch.bfloat16:
-        raise NotImplementedError(f"vtx.set_stream('fp32') covers the divided space-time blocks only, not {what}")
+        raise NotImplementedError(f"vtx.set_stream('fp32') does not cover {what}")
 
 
 def _drop_scale(layer_drop, rows, ndim, device):
@@ -325,12 +334,13 @@ class MultiheadAttentionWithPreNorm(nn.Module):
         if self.training:
             _no_dropout(self.proj_drop.p, 'proj_drop')
             _no_dropout(self.attn.attn_drop.p, 'attn_drop')
-        _no_exact('MultiheadAttentionWithPreNorm (space_only / joint_space_time / ViViT encoders)')
         x = _to_compute(query)
+        xs, exact = _stream_of(query)
         s = None if return_attention else _drop_scale(self.layer_drop, x.shape[0], 3, x.device)
-        return F_.SelfAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
-                                   self.attn.proj.weight, self.attn.proj.bias, self.num_heads, s,
-                                   bool(return_attention), self.norm.eps)
+        res = F_.SelfAttnFn.apply(x, self.norm.weight, self.norm.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+                                  self.attn.proj.weight, self.attn.proj.bias, self.num_heads, s,
+                                  bool(return_attention), self.norm.eps, xs, exact)
+        return res if return_attention else _with_stream(res, exact)
 
 
 class FFNWithPreNorm(nn.Module):

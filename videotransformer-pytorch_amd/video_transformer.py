@@ -15,7 +15,7 @@ import torch.nn as nn
 import vtx
 from vtx import functions as F_
 from vtx import ops
-from transformer import PatchEmbed, TransformerContainer, get_sine_cosine_pos_emb
+from transformer import PatchEmbed, TransformerContainer, get_sine_cosine_pos_emb, stream_value
 from weight_init import (trunc_normal_, init_from_vit_pretrain_, init_from_mae_pretrain_,
                          init_from_kinetics_pretrain_)
 from mvit import (PatchEmbeding, create_conv_patch_embed, create_multiscale_vision_transformers)  # noqa: F401
@@ -166,6 +166,7 @@ class TimeSformer(_VideoTransformerBase):
         x = self.transformer_layers(x)
         if self.attention_type == 'space_only':
             # mean over the frames of each clip before the norm (reference :247-249)
+            x = stream_value(x)
             n1, d = x.shape[1], x.shape[2]
             x32 = F_.CastFn.apply(x, torch.float32).reshape(b, -1, n1, d).mean(1)
             x = F_.CastFn.apply(x32, vtx.compute_dtype())
@@ -277,6 +278,7 @@ class ViViT(_VideoTransformerBase):
     def _fact_temporal_tokens(self, x, b):
         """Glue between the spatial and temporal encoders (reference :515-523), kept
         literal: the cls rows are the first b rows of the flattened (b t) axis."""
+        x = stream_value(x)                          # (the exact residual stream: the spatial encoder's stream as one tensor)
         D = x.shape[2]
         if D % 8 == 0 and D <= 1024 and x.dtype == vtx.compute_dtype():
             return F_.FactGlueFn.apply(x, _embed(self.time_embed, x.device), b)

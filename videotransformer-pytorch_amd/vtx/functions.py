@@ -479,8 +479,8 @@ class SelfAttnFn(torch.autograd.Function):
     x [Bn, L, D] -> x + DropPath(proj(attn(LN(x))))."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, heads, scale_vec, want_probs, eps=1e-5):
-        x = _chk(x)
+    def forward(ctx, x, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, heads, scale_vec, want_probs, eps=1e-5, xs=None, exact=False):
+        x = _chk(x)                                  # exact: the contribution d of the previous sub-block (see TimeAttnFn)
         Bn, L, D = x.shape
         M = Bn * L
         hd = D // heads
@@ -488,7 +488,12 @@ class SelfAttnFn(torch.autograd.Function):
         xn = _empty((M, D), x)
         mean = _empty((M,), x, torch.float32)
         rstd = _empty((M,), x, torch.float32)
-        ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        x32 = None
+        if exact:
+            x32 = torch.empty(Bn, L, D, dtype=torch.float32, device=x.device)
+            ops.layernorm_acc_fwd(xs, x, M, D, D, IDENT, x32, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
+        else:
+            ops.layernorm_fwd(x, M, D, D, IDENT, ln_w, ln_b, eps, xn, D, IDENT, mean, rstd)
         wq, wqT = weights(qkv_w, dtp, any(ctx.needs_input_grad))
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(xn, wq, qkv, M, 3 * D, D, bias=qkv_b)
@@ -501,22 +506,26 @@ class SelfAttnFn(torch.autograd.Function):
             return probs
         wp, wpT = weights(proj_w, dtp, any(ctx.needs_input_grad))
         out = torch.empty_like(x)
-        ops.gemm_nt(o, wp, out, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(L, 1, 1, 0), R=x)
-        ctx.save_for_backward(x, ln_w, mean, rstd, xn, qkv, o, lse,
+        ops.gemm_nt(o, wp, out, M, D, D, bias=proj_b, row_scale=scale_vec, rs=(L, 1, 1, 0), R=None if exact else x)
+        ctx.save_for_backward(x32 if exact else x, ln_w, mean, rstd, xn, qkv, o, lse,
                               scale_vec if scale_vec is not None else x.new_empty(0),
                               *[t for t in (wqT, wpT) if t is not None])
         ctx.cfg = (heads, scale_vec is not None)
+        if exact:
+            ctx.mark_non_differentiable(x32)
+            return out, x32
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstream=None):
         x, ln_w, mean, rstd, xn, qkv, o, lse, sv, wqT, wpT = ctx.saved_tensors
         heads, has_scale = ctx.cfg
         dout = _chk(dout)
         Bn, L, D = x.shape
         M = Bn * L
         hd = D // heads
-        dtp = x.dtype
+        dtp = dout.dtype
+        x_stream, x = x, dout                          # (the saved stream may be float32: buffers take dout's dtype)
         if has_scale:
             da = _empty((M, D), x)
             ops.row_scale_copy(dout, da, M, D, s=sv, rs=(L, 1, 1, 0))
@@ -533,8 +542,8 @@ class SelfAttnFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
         d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
-        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None)
+        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None, None)
 
 
 _compact = True
@@ -983,6 +992,24 @@ class FactGlueFn(torch.autograd.Function):
         de = torch.empty(1 + T, D, dtype=torch.float32, device=dh.device) if need_e else None
         dx = ops.fact_glue_bwd(dh, b, T, P, D, d_time_embed=de)
         return dx, (de.reshape(e_shape) if need_e else None), None
+
+
+class StreamValueFn(torch.autograd.Function):
+    """The exact residual stream as ONE bf16 tensor, for consumers outside the blocks (the ViViT fact-encoder glue, the
+    space_only frame mean): bf16(xs + d).  One rounding that nothing accumulates on; d(xs + d)/dd = 1."""
+
+    @staticmethod
+    def forward(ctx, d, xs):
+        d = _chk(d)
+        D = d.shape[-1]
+        rows = d.numel() // D
+        x32 = torch.empty(d.shape, dtype=torch.float32, device=d.device)
+        ops.layernorm_acc_fwd(xs, d, rows, D, D, IDENT, x32, D, IDENT)
+        return ops.cast_from_f32(x32, d.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
 
 
 class CastFn(torch.autograd.Function):
