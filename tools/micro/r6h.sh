@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R; export TMPDIR=/tmp
-timeout 900 python tools/merge_study.py 2>&1 | grep -v amdgpu.ids > $O/r6h_merge_study.txt; cat $O/r6h_merge_study.txt | cut -c1-250
+true
 rm -f $O/parity_report.txt
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/r6h_gpu_suite.log 2>&1; echo "pytest rc=$?" >> $O/r6h_gpu_suite.log
 tail -5 $O/r6h_gpu_suite.log | cut -c1-250
