@@ -3,7 +3,7 @@
 bf16 HIP path, one training step = forward + cross-entropy + backward (+ gradient
 all-reduce for N > 1) + SGD update, on N GPUs of one node (one process per GPU, RCCL).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames T] [--stream bf16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
@@ -39,7 +39,7 @@ import torch.distributed as dist  # noqa: E402
 FLOPS_FWD_BWD_PER_CLIP = {8: 1.175e12, 16: 2.352e12, 2: 0.2937e12}
 PEAK_BF16 = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0         # TB/s (spec; ~6.3 TB/s is what a streaming copy reaches)
-PMC_ROUNDS = ('round5_', 'round4_', 'round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
+PMC_ROUNDS = ('round6_', 'round5_', 'round4_', 'round3_', 'round2_')     # committed rocprofv3 counter passes of the default command, newest first
 
 
 def parse():
