@@ -156,17 +156,23 @@ def test_vivit_b_t16_exact_stream_vs_golden():
     assert e <= 1.5 * cal_entry('ViViT-B fact_encoder eval')['out'], f'eval deviation {e:.3e} beyond 1.5 x the reference autocast run'
 
 
-def test_recompute_refuses_the_exact_stream():
+def test_block_recompute_under_the_exact_stream():
+    """vtx.set_recompute(True) with the exact stream: the block's input carries the float32 stream as an attribute and the re-run in
+    backward reads it from the same object -- outputs and gradients bit-identical to the stored-activation run."""
     import vtx
     import video_transformer as V
-    m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
-    m.train()
-    vtx.set_recompute(True)
+    res = []
     try:
-        with pytest.raises(NotImplementedError):
-            m(synth.synth_clip(1, 4, 3, 64, 64, seed=2).to(DEV))
+        for rc in (False, True):
+            vtx.set_recompute(rc)
+            m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
+            y, grads = _train_step(m, synth.synth_clip(2, 4, 3, 64, 64, seed=2), 11, 128)
+            res.append((y.detach().clone(), {k: g.clone() for k, g in grads.items()}))
     finally:
         vtx.set_recompute(False)
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
 def test_timesformer_b_t8_exact_stream_vs_golden_and_reference_autocast():

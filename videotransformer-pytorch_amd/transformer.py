@@ -442,8 +442,8 @@ class TransformerContainer(nn.Module):
             if return_attention and idx >= last:
                 x = layer(x, return_attention=True)
             elif recompute:
-                _no_exact('vtx.set_recompute(True)')
-                # the CPU generator state is saved and restored around the re-run: DropPath draws the same masks
+                # the CPU generator state is saved and restored around the re-run: DropPath draws the same masks.  (Under the exact
+                # stream the block's input carries its float32 stream as an attribute; the re-run reads it from the same object.)
                 x = torch.utils.checkpoint.checkpoint(layer, x, use_reentrant=False)
             else:
                 x = layer(x)
