@@ -54,8 +54,8 @@ def set_stream(kind):
     """How the bf16 path keeps the residual stream: 'bf16' (default: every sub-block's x + f(x) is rounded to bf16 -- the fastest
     form, whose rounding of the running sum grows with sqrt(depth): 2x the reference's own autocast deviation on outputs at 12
     layers, 3x at 24) or 'fp32' (the exact stream: sub-blocks hand on their contribution, the running sum lives in float32 and is
-    advanced inside the next LayerNorm kernel -- what torch.autocast does in the reference; +1 GB of HBM traffic per sub-block at
-    96 clips).  TimeSformer / ViViT divided_space_time; the float32 precision mode is its own exact stream."""
+    advanced inside the next LayerNorm kernel -- what torch.autocast does in the reference; +0.7 GB of HBM traffic per sub-block at
+    96 clips, +4 % step time).  Every attention type of TimeSformer / ViViT; the float32 precision mode is its own exact stream."""
     if kind not in ('bf16', 'fp32'):
         raise ValueError(kind)
     functions.set_exact_stream(kind == 'fp32')
