@@ -1,11 +1,12 @@
 """Drop-in API surface: class names, constructor kwargs, state_dict keys, error behaviour."""
 import inspect
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from helpers import gold_keys
+from helpers import ROOT, gold_keys
 
 
 def test_state_dict_contract_timesformer_b():
@@ -130,3 +131,23 @@ def test_product_path_never_touches_the_oracle():
                 assert not oracle_importers(os.path.join(dirpath, f)), f'{f} imports the oracle'
     assert oracle_importers(os.path.join(ROOT, 'bench.py')) <= {'cpu_baseline', 'cpu_baseline_subprocess', '_cpu_baseline_main'}
     assert oracle_importers(os.path.join(ROOT, '__graft_entry__.py')) <= {'smoke'}
+
+
+def test_stream_switch_and_its_environment_variable():
+    """vtx.set_stream: 'bf16' (default) / 'fp32' (the exact residual stream), anything else raises; VTX_STREAM gives the initial
+    value for entry points that keep the reference's flag list (model_pretrain.py)."""
+    import subprocess
+    import sys
+    import vtx
+    assert vtx.get_stream() == 'bf16'
+    vtx.set_stream('fp32')
+    try:
+        assert vtx.get_stream() == 'fp32' and vtx.functions.exact_stream()
+        with pytest.raises(ValueError):
+            vtx.set_stream('fp16')
+    finally:
+        vtx.set_stream('bf16')
+    pkg = os.path.join(ROOT, 'videotransformer-pytorch_amd')
+    out = subprocess.run([sys.executable, '-c', f'import sys; sys.path.insert(0, {pkg!r}); import vtx; print(vtx.get_stream())'],
+                         env=dict(os.environ, VTX_STREAM='fp32'), capture_output=True, text=True, check=True).stdout
+    assert out.strip().endswith('fp32')
