@@ -162,6 +162,47 @@ def test_static_unused_parameters_release_their_buckets():
     assert torch.allclose(ret[0]['grad'], torch.full((4, 4), 3.0)) and torch.equal(ret[0]['grad'], ret[1]['grad'])
 
 
+def _worker_bf16_wire(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vtx import dp
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(8, 8)
+    buckets = dp.GradBuckets(lin.parameters(), comm_dtype=torch.bfloat16)
+    ptrs = []
+    try:
+        for step in range(2):
+            buckets.zero()
+            (lin(torch.ones(2, 8) * (rank + 1 + step))).sum().backward()
+            buckets.finish()
+            ptrs.append(buckets.buckets[0]['comm_buf'].data_ptr())
+        ret[rank] = ('ok', lin.weight.grad.clone(), ptrs)
+    except RuntimeError as e:                           # a gloo build without bfloat16 reductions
+        ret[rank] = ('unsupported: ' + str(e)[:80], None, ptrs)
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_format_reuses_one_buffer_per_bucket():
+    """GradBuckets(comm_dtype=torch.bfloat16): the gradients travel as bf16 (half the xGMI bytes, lossy) through ONE persistent
+    buffer per bucket, and come back as the rank mean within bf16 rounding."""
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_bf16_wire, args=(2, port, ret), nprocs=2, join=True)
+    if ret[0][0] != 'ok':
+        pytest.skip('this gloo build does not reduce bfloat16: ' + ret[0][0])
+    for r in range(2):
+        status, g, ptrs = ret[r]
+        assert ptrs[0] == ptrs[1], 'the wire buffer is allocated once'
+        # step 1: rank r feeds x = r + 2 to both rows: d/dW = 2 x per weight column; mean over ranks = 2 * 2.5 = 5
+        assert torch.allclose(g, torch.full((8, 8), 5.0), rtol=1e-2), g
+    assert torch.equal(ret[0][1], ret[1][1])
+
+
 def test_shard_clips_partition():
     sys.path.insert(0, os.path.join(ROOT, 'videotransformer-pytorch_amd'))
     from vtx import dp

