@@ -309,19 +309,19 @@ def other_configs(dev, model8, head8, budget_s=40.0):
     # the headline model at the batch the reference trains at (8 clips per GPU, demo log) and at 32 clips
     for b in (8, 32):
         run('TimeSformer-B divided_space_time, 8x3x224x224, bf16, fwd+CE+bwd+SGD (headline model, %d clips per GPU)' % b,
-            classifier(model8, head8), b, 8, FLOPS_FWD_BWD_PER_CLIP[8])
+            classifier(model8, head8), b, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=12, warmup=3)
     # the headline model and batch with the EXACT residual stream (vtx.set_stream('fp32'): the running sum of the residual stream in
     # float32 as under the reference's autocast) -- what the accuracy mode costs
     vtx.set_stream('fp32')
     try:
         run("TimeSformer-B divided_space_time, 8x3x224x224, bf16 with the exact float32 residual stream (vtx.set_stream('fp32')), fwd+CE+bwd+SGD, 96 clips per GPU",
-            classifier(model8, head8), 96, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=4, warmup=2)
+            classifier(model8, head8), 96, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=6, warmup=2)
     finally:
         vtx.set_stream('bf16')
     run('TimeSformer-B divided_space_time, 16x3x224x224, bf16, fwd+CE+bwd+SGD (north_star second shape)',
         classifier(*fresh(lambda: V.TimeSformer(num_frames=16))), 48, 16, FLOPS_FWD_BWD_PER_CLIP[16])
     run('ViViT-B fact_encoder, Conv3d tubelet 2, 16x3x224x224, bf16, fwd+CE+bwd+SGD (BASELINE configs[2])',
-        classifier(*fresh(lambda: V.ViViT(num_frames=16))), 32, 16, 0.850e12)
+        classifier(*fresh(lambda: V.ViViT(num_frames=16))), 32, 16, 0.850e12, steps=8)
 
     # BASELINE configs[4]: TimeSformer-L (D 1024, 16 heads, 24 layers) on 96-frame clips -- 18 817 tokens per clip, every activation
     # stored (no recompute: 2.1 GB per layer and clip, ~84 GB at 4 clips of the 288).  FLOPs per clip fwd+bwd: the Linears
