@@ -10,6 +10,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_under_rocprof.log 2>&1
 python $R/tools/rocpd_stats.py /tmp/prof_kt > $O/${TAG}_rocprofv3_kernel_stats_b96.csv
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_exact -- python $R/bench.py --stream fp32 --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_exact_under_rocprof.log 2>&1
+python $R/tools/rocpd_stats.py /tmp/prof_kt_exact > $O/${TAG}_rocprofv3_kernel_stats_exact_b96.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C -d /tmp/prof_$C -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-other-configs > /tmp/log_$C.txt 2>&1
   python $R/tools/pmc_dump.py /tmp/prof_$C > $O/${TAG}_pmc_${C}_b96.txt
