@@ -201,8 +201,9 @@ def _ln_grad_buffers(ln_w, ln_b, D, device):
 # vtx.set_stream('fp32'): a sub-block returns its CONTRIBUTION d = f(x) (bf16) next to the float32 stream it read, and the next
 # sub-block's LayerNorm kernel forms x = xs + d in float32 (vtx_layernorm_acc_fwd) -- no bf16 rounding of the running sum.  The
 # float32 stream is a side buffer, not an autograd tensor: gradients flow through the chain of contributions exactly as they
-# flow through the bf16 stream (d(xs + d)/dd = 1), so every backward below is shared between the two modes.  TimeSformer /
-# ViViT divided_space_time blocks only (the other attention types raise).
+# flow through the bf16 stream (d(xs + d)/dd = 1), so every backward below is shared between the two modes.  Every attention
+# type of TimeSformer / ViViT (readers that need the stream as ONE tensor -- the space_only frame mean, the ViViT fact-encoder
+# glue -- take it through StreamValueFn); MViT keeps its bf16 stream.
 _exact = False
 
 
