@@ -12,6 +12,7 @@ and prints, per arm, the loss at every step and -- after K steps -- the relative
 (the drift of the training trajectory) and of the model output on a held-out clip.
 
     python tools/train_parity.py [--steps 12] [--layers 6] [--lr 0.02] [--seeds 3]
+    python tools/train_parity.py --full 1 [--steps 6] [--batch 4] [--seeds 1]      # TimeSformer-B itself: D 768, 12 layers, 8 x 224^2 clips
 """
 import os
 import sys
@@ -32,17 +33,22 @@ def main():
     from vtx import optim
     from oracle import synth, vt_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 8, 16))
-    cfg = dict(num_frames=4, img_size=64, patch_size=16, embed_dims=128, num_heads=2, num_transformer_layers=L)
-    B = 4
-    print(f'TimeSformer divided_space_time D 128, {L} layers, 4 x 64^2 clips, batch {B}, {K} SGD(nesterov, lr {lr}, momentum 0.9) steps, DropPath 0.1, '
-          f'loss 0.5 |y - t|^2; distances are relative L2 over ALL parameters / the held-out output, against the fp32 oracle arm')
+    full = opt('--full', 0)
+    if full:
+        L, T, S, D, H = 12, 8, 224, 768, 12
+    else:
+        T, S, D, H = 4, 64, 128, 2
+    cfg = dict(num_frames=T, img_size=S, patch_size=16, embed_dims=D, num_heads=H, num_transformer_layers=L)
+    B = opt('--batch', 4)
+    print(f'TimeSformer divided_space_time D {D}, {L} layers, {T} x {S}^2 clips, batch {B}, {K} SGD(nesterov, lr {lr}, momentum 0.9) steps, DropPath 0.1, '
+          f'loss 0.5 |y - t|^2; distances are relative L2 over ALL parameters / the held-out output, against the fp32 oracle arm', flush=True)
     tot = {}
     for seed in range(nseeds):
         shapes = synth.shapes_of(V.TimeSformer(**cfg))
         sd0 = synth.synth_state_dict(shapes, seed)
-        x = synth.synth_clip(B, 4, 3, 64, 64, seed=10 + seed)
-        xh = synth.synth_clip(2, 4, 3, 64, 64, seed=50 + seed)
-        tgt = synth.synth_tensor('target', (B, 128), seed) * 0.5
+        x = synth.synth_clip(B, T, 3, S, S, seed=10 + seed)
+        xh = synth.synth_clip(2, T, 3, S, S, seed=50 + seed)
+        tgt = synth.synth_tensor('target', (B, D), seed) * 0.5
 
         def run_oracle(autocast):
             ps = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
@@ -52,13 +58,13 @@ def main():
                 o.zero_grad()
                 torch.manual_seed(1000 + step)
                 with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
-                    y = O.timesformer_forward(ps, x, 4, heads=2, layers=L, training=True)
+                    y = O.timesformer_forward(ps, x, T, heads=H, layers=L, training=True)
                 loss = 0.5 * ((y.float() - tgt) ** 2).sum()
                 loss.backward()
                 o.step()
                 losses.append(loss.item())
             with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
-                yh = O.timesformer_forward(ps, xh, 4, heads=2, layers=L).float()
+                yh = O.timesformer_forward(ps, xh, T, heads=H, layers=L).float()
             return {k: v.detach() for k, v in ps.items()}, yh, losses
 
         def run_vtx(stream):
