@@ -3,7 +3,7 @@
 bf16 HIP path, one training step = forward + cross-entropy + backward (+ gradient
 all-reduce for N > 1) + SGD update, on N GPUs of one node (one process per GPU, RCCL).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames T] [--stream bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--frames T] [--stream bf16|fp32|fp32+grad]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
@@ -50,8 +50,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=96, help='clips per GPU (weak scaling)')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--stream', default='bf16', choices=['bf16', 'fp32'],
-                    help="residual stream of the bf16 path: bf16 (default, the headline) or fp32 = vtx.set_stream('fp32'), the exact stream (DESIGN.md 3)")
+    ap.add_argument('--stream', default='bf16', choices=['bf16', 'fp32', 'fp32+grad'],
+                    help="residual stream of the bf16 path: bf16 (default, the headline), fp32 = vtx.set_stream('fp32'), the exact stream, or fp32+grad = its gradient in float32 too (DESIGN.md 3)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true', help='skip the instrumented per-kernel-class pass')
     ap.add_argument('--no-other-configs', action='store_true',

@@ -106,6 +106,14 @@ int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, long lddy, vtx
                       const void* x, long ldx, vtx_rowmap xmap, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, void* dx, long lddx,
                       float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
+/* The float32 GRADIENT stream of the bf16 kernels (round 6; with vtx_layernorm_acc_fwd the residual stream is float32 in both
+ * directions, as it is under the reference's torch.autocast where `x = x + drop_path(f(norm(x)))` (transformer.py:281,381,455,522)
+ * adds bf16 branch outputs to a float32 x and autograd sums the branch gradients in float32):
+ *   dx32[xmap(m)] = dres32[xmap(m)] + LN'(dy[m])  in float32,   dx[xmap(m)] = bf16(dx32[xmap(m)])
+ * dy, dx bf16; x the float32 stream; dres32 / dx32 / dx share xmap and lddx; D <= 1024; same workspace as vtx_layernorm_bwd. */
+int vtx_layernorm_bwd_g32(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap, const float* x, long ldx, vtx_rowmap xmap,
+                          const float* mean, const float* rstd, const float* gamma, const float* dres32, float* dx32,
+                          void* dx, long lddx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, void* stream);
 
 /* ----------------------------------------------------------------------- GEMM
  * C[M,N] = epilogue(A[M,K] * B[N,K]^T).  Replaces every nn.Linear forward and

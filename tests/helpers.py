@@ -101,7 +101,7 @@ def sample_idx(numel):
     return torch.arange(0, min(NS, numel)) * step
 
 
-def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_cal=False, cal=None, widen=True):
+def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_cal=False, cal=None, widen=True, collect=None):
     """named_grads: {param_name: grad tensor}; g: golden npz ('g:' whole small tensors, 'gs:' 4096 strided samples
     or 'gh:' the first 256 elements of large ones, 'gn:' their norm and sum).
     fp32 path (exact_elements): every element within tol of max|ref| (the 1e-3 bar).
@@ -141,6 +141,8 @@ def compare_grads(prefix, named_grads, g, tol, exact_elements=False, autocast_ca
         e_l2 = max((got - ref).norm().item() / max(ref_norm, 1e-30), norm_err)
         n += 1
         worst_l2, worst_max = max(worst_l2, e_l2), max(worst_max, e_max)
+        if collect is not None:                      # per-tensor relative L2 errors for the caller (two modes side by side)
+            collect[name] = e_l2
         tol_k = tol
         if cal_grad is not None:
             tol_k = max(tol, min(AUTOCAST_FACTOR * cal_grad[name], WIDEN_CAP * tol)) if widen else tol

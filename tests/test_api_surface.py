@@ -134,7 +134,8 @@ def test_product_path_never_touches_the_oracle():
 
 
 def test_stream_switch_and_its_environment_variable():
-    """vtx.set_stream: 'bf16' (default) / 'fp32' (the exact residual stream), anything else raises; VTX_STREAM gives the initial
+    """vtx.set_stream: 'bf16' (default) / 'fp32' (the exact residual stream) / 'fp32+grad' (its gradient in float32 too), anything
+    else raises; VTX_STREAM gives the initial
     value for entry points that keep the reference's flag list (model_pretrain.py)."""
     import subprocess
     import sys
@@ -142,12 +143,16 @@ def test_stream_switch_and_its_environment_variable():
     assert vtx.get_stream() == 'bf16'
     vtx.set_stream('fp32')
     try:
-        assert vtx.get_stream() == 'fp32' and vtx.functions.exact_stream()
+        assert vtx.get_stream() == 'fp32' and vtx.functions.exact_stream() and not vtx.functions.exact_grad_stream()
+        vtx.set_stream('fp32+grad')
+        assert vtx.get_stream() == 'fp32+grad' and vtx.functions.exact_stream() and vtx.functions.exact_grad_stream()
+        vtx.set_stream('bf16')
+        assert not vtx.functions.exact_stream() and not vtx.functions.exact_grad_stream()
         with pytest.raises(ValueError):
             vtx.set_stream('fp16')
     finally:
         vtx.set_stream('bf16')
     pkg = os.path.join(ROOT, 'videotransformer-pytorch_amd')
     out = subprocess.run([sys.executable, '-c', f'import sys; sys.path.insert(0, {pkg!r}); import vtx; print(vtx.get_stream())'],
-                         env=dict(os.environ, VTX_STREAM='fp32'), capture_output=True, text=True, check=True).stdout
-    assert out.strip().endswith('fp32')
+                         env=dict(os.environ, VTX_STREAM='fp32+grad'), capture_output=True, text=True, check=True).stdout
+    assert out.strip().endswith('fp32+grad')

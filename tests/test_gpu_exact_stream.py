@@ -156,15 +156,18 @@ def test_vivit_b_t16_exact_stream_vs_golden():
     assert e <= 1.5 * cal_entry('ViViT-B fact_encoder eval')['out'], f'eval deviation {e:.3e} beyond 1.5 x the reference autocast run'
 
 
-def test_block_recompute_under_the_exact_stream():
+@pytest.mark.parametrize('mode', ['fp32', 'fp32+grad'])
+def test_block_recompute_under_the_exact_stream(mode):
     """vtx.set_recompute(True) with the exact stream: the block's input carries the float32 stream as an attribute and the re-run in
-    backward reads it from the same object -- outputs and gradients bit-identical to the stored-activation run."""
+    backward reads it from the same object -- outputs and gradients bit-identical to the stored-activation run ('fp32+grad': the
+    float32 gradient rides on the gradient tensors between the same backward nodes, recompute or not)."""
     import vtx
     import video_transformer as V
     res = []
     try:
         for rc in (False, True):
             vtx.set_recompute(rc)
+            vtx.set_stream(mode)
             m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
             y, grads = _train_step(m, synth.synth_clip(2, 4, 3, 64, 64, seed=2), 11, 128)
             res.append((y.detach().clone(), {k: g.clone() for k, g in grads.items()}))
@@ -173,6 +176,43 @@ def test_block_recompute_under_the_exact_stream():
     assert torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_float32_gradient_stream_survives_only_on_the_unmodified_tensor():
+    """The float32 gradient rides on the bf16 gradient tensor as an attribute with that tensor's version counter: a second consumer of
+    a block's output makes autograd ACCUMULATE into the tensor (in place: the version moves; out of place: another object) -- the
+    stale float32 buffer must then be dropped and the stream's gradient restarted from the accumulated bf16 tensor."""
+    import vtx
+    from vtx import functions as F_
+    vtx.set_stream('fp32+grad')
+    d = torch.randn(2, 5, 128, device=DEV).bfloat16()
+    xs = torch.randn(2, 5, 128, device=DEV)
+    g32 = torch.randn(2, 5, 128, device=DEV)
+    d._vtx_g32 = (g32, d._version)
+    assert F_._grad_stream(d, xs) is g32
+    d.add_(1)                                                    # what InputBuffer::add does to the first gradient
+    fresh = F_._grad_stream(d, xs)
+    assert fresh is not g32 and torch.equal(fresh, d.float())
+    assert F_._grad_stream(d.clone(), xs) is not g32               # another object: no attribute
+    vtx.set_stream('fp32')
+    assert F_._grad_stream(d, xs) is None                        # mode off
+    # end to end: a tap on the stream between two blocks (a second consumer) still gives the right gradients
+    import video_transformer as V
+    grads = {}
+    for mode in ('fp32', 'fp32+grad'):
+        vtx.set_stream(mode)
+        m, _ = _build(V.TimeSformer, 3, num_frames=4, **SMALL)
+        m.train(); m.zero_grad()
+        taps = []
+        h = m.transformer_layers.layers[1].register_forward_hook(lambda mod, inp, out: taps.append(out))
+        torch.manual_seed(11)
+        y = m(synth.synth_clip(2, 4, 3, 64, 64, seed=2).to(DEV))
+        h.remove()
+        (y.float().sum() + 0.5 * taps[0].float().sum()).backward()
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for k in grads['fp32']:
+        e = relerr(grads['fp32+grad'][k].cpu(), grads['fp32'][k].cpu())
+        assert e < 2e-2, (k, e)
 
 
 def test_timesformer_b_t8_exact_stream_vs_golden_and_reference_autocast():
@@ -252,3 +292,97 @@ def test_bench_stack_exact_stream_with_partial_ffn_drop():
         worst = max(worst, e)
         assert e <= TOL_BF16_GRAD, f'{k}: {e:.3e}'
     report(f'bench stack bf16 exact stream: worst parameter gradient l2-rel {worst:.3e}')
+
+
+# ---- 'fp32+grad': the stream's gradient in float32 too ---------------------------------------------------------------------
+
+def test_layernorm_bwd_g32_vs_float64():
+    """vtx_layernorm_bwd_g32: dx32 = dres32 + LayerNorm-backward(dy) in float32 on the mapped rows, dx = bf16(dx32) EXACTLY (one
+    rounding of the float32 sum), dgamma / dbeta as vtx_layernorm_bwd; rows outside the map untouched."""
+    from vtx import ops
+    for D in (128, 200, 768, 1024):
+        B, N = 3, 37
+        x = (rnd(B, 1 + N, D, seed=1) * 2 + 0.5)
+        gamma = 1 + 0.1 * rnd(D, seed=2)
+        dy = rnd(B * N, D, seed=4).bfloat16()
+        dres32 = rnd(B, 1 + N, D, seed=5) * 3
+        xq = x.double().requires_grad_(True)
+        gq, bq = gamma.double().requires_grad_(True), torch.zeros(D, dtype=torch.float64, requires_grad=True)
+        ref = torch.nn.functional.layer_norm(xq[:, 1:], (D,), gq, bq, 1e-5).reshape(B * N, D)
+        ref.backward(dy.double())
+        dx_ref = xq.grad + dres32.double()
+        tm = ops.tokmap(N)
+        xd = x.to(DEV)
+        mean = xd[:, 1:].mean(-1).reshape(-1).contiguous()
+        rstd = (xd[:, 1:].var(-1, unbiased=False) + 1e-5).rsqrt().reshape(-1).contiguous()
+        dx = torch.full((B, 1 + N, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        dx32 = torch.full((B, 1 + N, D), 7.0, device=DEV)
+        dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        ops.layernorm_bwd(dy.to(DEV), D, ops.IDENT, xd, D, tm, B * N, D, mean, rstd, gamma.to(DEV), None, dx, D, dg, db,
+                          dres32=dres32.to(DEV), dx32=dx32)
+        torch.cuda.synchronize()
+        check(f'ln_bwd_g32 dx32 D={D}', dx32[:, 1:].cpu(), dx_ref[:, 1:], 1e-5)
+        assert torch.equal(dx[:, 1:].cpu(), dx32[:, 1:].bfloat16().cpu()), 'dx is the single rounding of the float32 sum'
+        assert bool((dx32[:, 0] == 7).all()) and bool((dx[:, 0] == 7).all()), 'the cls rows are outside the token map'
+        check(f'ln_bwd_g32 dgamma D={D}', dg.cpu(), gq.grad, 1e-2)
+        check(f'ln_bwd_g32 dbeta D={D}', db.cpu(), bq.grad, 1e-2)
+
+
+def _grads_of(V, cls, nblk, at, x, seed, stream, **kw):
+    import vtx
+    vtx.set_stream(stream)
+    m, _ = _build(cls, nblk, attention_type=at, **kw)
+    return _train_step(m, x, seed, 128)
+
+
+@pytest.mark.parametrize('case', ['tsf divided_space_time', 'tsf joint_space_time', 'vivit fact_encoder', 'vivit divided_space_time'])
+def test_float32_gradient_stream_vs_golden(case):
+    """vtx.set_stream('fp32+grad') against the reference goldens with the FIXED bars: outputs bit-identical to 'fp32' (the forward is
+    the same), the gradients no worse at the median than under 'fp32'; the gradient of the FIRST tensors of the backward chain (patch
+    embedding, position embedding: they see the whole stream's gradient) closer to the reference than with the bf16 gradient stream."""
+    import vtx
+    import video_transformer as V
+    fam, at = case.split()
+    if fam == 'tsf':
+        cls, nblk, x, seed, kw, gname = V.TimeSformer, 3, synth.synth_clip(3, 4, 3, 64, 64, seed=2), 11, dict(num_frames=4, **SMALL), f'tsf_small_{at}'
+    else:
+        cls, nblk, x, seed, kw, gname = V.ViViT, 4, synth.synth_clip(3, 8, 3, 64, 64, seed=5), 13, dict(num_frames=8, **SMALL), f'vivit_small_{at}'
+    g = gold(gname + '.npz')
+    y1, g1 = _grads_of(V, cls, nblk, at, x, seed, 'fp32', **kw)
+    y2, g2 = _grads_of(V, cls, nblk, at, x, seed, 'fp32+grad', **kw)
+    assert vtx.get_stream() == 'fp32+grad'
+    assert torch.equal(y1, y2), 'the forward does not depend on the gradient stream'
+    c1, c2 = {}, {}
+    cal = f'{gname.replace("_small_", "_small ")} train'
+    compare_grads(f'{gname} bf16 exact stream (again)', g1, g, TOL_BF16_GRAD, cal=cal, widen=False, collect=c1)
+    compare_grads(f'{gname} bf16 exact stream + float32 gradient stream', g2, g, TOL_BF16_GRAD, cal=cal, widen=False, collect=c2)
+    e1, e2 = [c1[k] for k in c1], [c2[k] for k in c1]
+    med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
+    report(f'     {case}: median / worst gradient l2-rel  fp32 stream {med(e1):.3e} / {max(e1):.3e}   + float32 gradient stream {med(e2):.3e} / {max(e2):.3e}'
+           f'   ({sum(b < a for a, b in zip(e1, e2))} of {len(e1)} tensors closer to the reference)')
+    assert med(e2) <= 1.10 * med(e1), (med(e1), med(e2))      # 3 - 4 layers: the two gradient streams differ by rounding noise only
+
+
+@pytest.mark.parametrize('case', ['TimeSformer-B T=8', 'ViViT-B T=16'])
+def test_float32_gradient_stream_full_size(case):
+    """BASELINE configs[1] / [2] at full size (12 layers: 36 / 32 sub-blocks of gradient stream) under 'fp32+grad': every gradient
+    inside the FIXED bars, the median no worse than under 'fp32', and the report carries both modes next to the reference's autocast."""
+    import vtx
+    import video_transformer as V
+    if case.startswith('Time'):
+        g, build, x, seed = gold('tsf_b_t8_autocast.npz'), (lambda: _build(V.TimeSformer, 0, num_frames=8)[0]), synth.synth_clip(1, 8, seed=1), 7
+    else:
+        g, build, x, seed = gold('vivit_b_t16_train.npz'), (lambda: _build(V.ViViT, 0, num_frames=16)[0]), synth.synth_clip(2, 16, seed=3), 17
+    c = {}
+    for mode in ('fp32', 'fp32+grad'):
+        vtx.set_stream(mode)
+        y, grads = _train_step(build(), x, seed, 768)
+        check(f'{case} train bf16 stream {mode} out', y.cpu(), g['out'], TOL_BF16)
+        c[mode] = {}
+        kw = dict(autocast_cal=True) if case.startswith('Time') else dict(cal='ViViT-B T=16 train', widen=False)
+        compare_grads(f'{case} train bf16 stream {mode}', grads, g, TOL_BF16_GRAD, collect=c[mode], **kw)
+    e1, e2 = [c['fp32'][k] for k in c['fp32']], [c['fp32+grad'][k] for k in c['fp32']]
+    med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
+    report(f'     {case}: median / worst gradient l2-rel  fp32 stream {med(e1):.3e} / {max(e1):.3e}   + float32 gradient stream {med(e2):.3e} / {max(e2):.3e}'
+           f'   ({sum(b < a for a, b in zip(e1, e2))} of {len(e1)} tensors closer to the reference)')
+    assert med(e2) <= 1.03 * med(e1), (med(e1), med(e2))

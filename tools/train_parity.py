@@ -7,12 +7,14 @@ with a bounded loss (0.5 |y - target|^2) and DropPath on (the same CPU draws in 
     oracle + autocast    the same graph under torch.autocast('cpu', bfloat16): what the reference's AMP does
     vtx bf16             this library, bf16 kernels, bf16 residual stream (the default, the benchmarked mode)
     vtx bf16 exact       this library, bf16 kernels, vtx.set_stream('fp32')
+    vtx exact + grad     ... vtx.set_stream('fp32+grad'): the stream's gradient in float32 too
 
 and prints, per arm, the loss at every step and -- after K steps -- the relative L2 distance of ALL parameters from the fp32 oracle's
 (the drift of the training trajectory) and of the model output on a held-out clip.
 
     python tools/train_parity.py [--steps 12] [--layers 6] [--lr 0.02] [--seeds 3]
     python tools/train_parity.py --full 1 [--steps 6] [--batch 4] [--seeds 1]      # TimeSformer-B itself: D 768, 12 layers, 8 x 224^2 clips
+    python tools/train_parity.py --model vivit [--full 1]                          # ViViT fact_encoder, Conv3d tubelets (full: ViViT-B, 16 x 224^2)
 """
 import os
 import sys
@@ -34,17 +36,25 @@ def main():
     from oracle import synth, vt_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 8, 16))
     full = opt('--full', 0)
+    top = opt('--top', 0)
+    which = opt('--model', 'timesformer')
+    vivit = which == 'vivit'
     if full:
-        L, T, S, D, H = 12, 8, 224, 768, 12
+        L, T, S, D, H = 12, (16 if vivit else 8), 224, 768, 12
     else:
-        T, S, D, H = 4, 64, 128, 2
+        T, S, D, H = (8 if vivit else 4), 64, 128, 2
     cfg = dict(num_frames=T, img_size=S, patch_size=16, embed_dims=D, num_heads=H, num_transformer_layers=L)
+    Model = V.ViViT if vivit else V.TimeSformer
+    if vivit:
+        cfg.update(attention_type='fact_encoder', conv_type='Conv3d', tube_size=2)
+    fwd = ((lambda ps, xx, training=False: O.vivit_forward(ps, xx, T, tube_size=2, heads=H, layers=L, training=training)) if vivit else
+           (lambda ps, xx, training=False: O.timesformer_forward(ps, xx, T, heads=H, layers=L, training=training)))
     B = opt('--batch', 4)
-    print(f'TimeSformer divided_space_time D {D}, {L} layers, {T} x {S}^2 clips, batch {B}, {K} SGD(nesterov, lr {lr}, momentum 0.9) steps, DropPath 0.1, '
+    print(f'{"ViViT fact_encoder (Conv3d tubelet 2)" if vivit else "TimeSformer divided_space_time"} D {D}, {L} layers, {T} x {S}^2 clips, batch {B}, {K} SGD(nesterov, lr {lr}, momentum 0.9) steps, DropPath 0.1, '
           f'loss 0.5 |y - t|^2; distances are relative L2 over ALL parameters / the held-out output, against the fp32 oracle arm', flush=True)
     tot = {}
     for seed in range(nseeds):
-        shapes = synth.shapes_of(V.TimeSformer(**cfg))
+        shapes = synth.shapes_of(Model(**cfg))
         sd0 = synth.synth_state_dict(shapes, seed)
         x = synth.synth_clip(B, T, 3, S, S, seed=10 + seed)
         xh = synth.synth_clip(2, T, 3, S, S, seed=50 + seed)
@@ -58,19 +68,19 @@ def main():
                 o.zero_grad()
                 torch.manual_seed(1000 + step)
                 with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
-                    y = O.timesformer_forward(ps, x, T, heads=H, layers=L, training=True)
+                    y = fwd(ps, x, training=True)
                 loss = 0.5 * ((y.float() - tgt) ** 2).sum()
                 loss.backward()
                 o.step()
                 losses.append(loss.item())
             with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
-                yh = O.timesformer_forward(ps, xh, T, heads=H, layers=L).float()
+                yh = fwd(ps, xh).float()
             return {k: v.detach() for k, v in ps.items()}, yh, losses
 
-        def run_vtx(stream):
-            vtx.set_precision('bf16')
+        def run_vtx(stream, precision='bf16'):
+            vtx.set_precision(precision)
             vtx.set_stream(stream)
-            m = V.TimeSformer(**cfg)
+            m = Model(**cfg)
             m.load_state_dict(sd0, strict=True)
             m.to(DEV).train()
             o = optim.FusedSGD(m.parameters(), lr=lr, momentum=0.9, nesterov=True)
@@ -90,7 +100,10 @@ def main():
             return {k: v.detach().cpu() for k, v in m.state_dict().items()}, yh, losses
 
         ref_p, ref_y, ref_l = run_oracle(False)
-        arms = {'oracle + autocast': run_oracle(True), 'vtx bf16': run_vtx('bf16'), 'vtx bf16 exact': run_vtx('fp32')}
+        arms = {'oracle + autocast': run_oracle(True), 'vtx bf16': run_vtx('bf16'), 'vtx bf16 exact': run_vtx('fp32'),
+                'vtx exact + grad': run_vtx('fp32+grad')}
+        if opt('--fp32-arm', 0):
+            arms['vtx fp32 kernels'] = run_vtx('bf16', 'fp32')          # validates the harness: the same trajectory to float32 rounding
         flat = lambda p: torch.cat([p[k].double().flatten() for k in sorted(ref_p)])      # noqa: E731
         fr = flat(ref_p)
         moved = (fr - flat(sd0)).norm().item() / fr.norm().item()
@@ -102,6 +115,12 @@ def main():
             dl = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(ls, ref_l))
             print(f'   {name:18s} parameters {dp:.3e} of |w| = {dstep:.3e} of the distance travelled; held-out output {dy:.3e}; worst loss deviation {dl:.3e}; '
                   f'final loss {ls[-1]:.4f}')
+            if top:
+                tot2 = (flat(p) - fr).norm().item() ** 2
+                per = sorted(((((p[k].double() - ref_p[k].double()).norm().item() ** 2) / tot2, k) for k in ref_p), reverse=True)[:top]
+                print('      largest shares of the squared drift: ' + '; '.join(
+                    f'{k} {sh:.2f} (rel {(p[k].double() - ref_p[k].double()).norm().item() / max((ref_p[k].double() - sd0[k].double()).norm().item(), 1e-30):.2e} of its own travel)'
+                    for sh, k in per))
             t = tot.setdefault(name, [0.0, 0.0, 0.0])
             t[0] += dstep / nseeds; t[1] += dy / nseeds; t[2] += dl / nseeds
     print('means over the seeds:')

@@ -341,14 +341,20 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_acc_fwd_kernel(
 // is branch free -- with exec-masked loads in it hipcc falls back to vmcnt(0) waits and the prefetch is lost.
 // TX: the type x is stored in -- T, or float for the bf16 kernels under the exact residual stream (vtx_layernorm_acc_fwd below keeps
 // the stream in float32; gradients stay T)
-template <typename T, int NCH, bool FULL, bool RES, typename TX = T>
+// G32 (with RES): the GRADIENT of the residual stream is float32 too -- the residual gradient is read from `dres32`, the sum
+// dres32 + LayerNorm-backward goes to `dx32` in float32 and, rounded ONCE, to `dx` (what the GEMMs of the sub-block before read):
+// the running sum of the stream's gradient is never rounded to T (vtx_layernorm_bwd_g32)
+template <typename T, int NCH, bool FULL, bool RES, typename TX = T, bool G32 = false>
 __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && sizeof(TX) == 2 && NCH <= 3) ? 3 : 1) void ln_bwd_kernel(
     int rows, int D, const T* __restrict__ dy, long lddy, vtx_rowmap dymap,
     const TX* __restrict__ x, long ldx, vtx_rowmap xmap, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ dres,
-    T* __restrict__ dx, long lddx, float* __restrict__ part) {
+    T* __restrict__ dx, long lddx, float* __restrict__ part, const float* __restrict__ dres32 = nullptr,
+    float* __restrict__ dx32 = nullptr) {
+  static_assert(!G32 || RES, "G32: a residual gradient is always present");
   typedef typename Raw4<T>::type raw_t;
   typedef typename Raw4<TX>::type rawx_t;
+  typedef typename Raw4<typename std::conditional<G32, float, T>::type>::type rawr_t;
   __shared__ float red[LN_WAVES][2][NCH * 256];
   __shared__ float gsm[NCH * 256];                 // gamma: read per row from LDS instead of held in 4*NCH registers
   const int lane = threadIdx.x & 63;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && sizeof(TX) == 2 &
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
-  struct Row { rawx_t x[NCH]; raw_t dy[NCH], dr[NCH]; float mu, rs; long pr; };
+  struct Row { rawx_t x[NCH]; raw_t dy[NCH]; rawr_t dr[NCH]; float mu, rs; long pr; };
   auto fetch = [&](long r, Row& w) {
     w.pr = map_row(xmap, r);
     const TX* xr = x + w.pr * ldx;
@@ -375,7 +381,8 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && sizeof(TX) == 2 &
       if (FULL || col < D) {
         w.x[c] = ld_raw_nt(reinterpret_cast<const rawx_t*>(xr + col));
         w.dy[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(dyr + col));
-        if (RES) w.dr[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(drr + col));
+        if constexpr (G32) w.dr[c] = ld_raw_nt(reinterpret_cast<const rawr_t*>(dres32 + w.pr * lddx + col));
+        else if (RES) w.dr[c] = ld_raw_nt(reinterpret_cast<const raw_t*>(drr + col));
       }
     }
   };
@@ -425,6 +432,7 @@ __global__ __launch_bounds__(LN_WAVES * 64, (sizeof(T) == 2 && sizeof(TX) == 2 &
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += rv[j];
         }
+        if constexpr (G32) st4<float>(dx32 + w.pr * lddx + col, o);
         st4<T>(dxr + col, o);
       }
     }
@@ -696,7 +704,7 @@ template <typename T, typename TX = T>
 static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap, const void* x,
                     long ldx, vtx_rowmap xmap, const float* mean, const float* rstd,
                     const float* gamma, const void* dres, void* dx, long lddx, float* part,
-                    int nblocks, int* launched, hipStream_t st) {
+                    int nblocks, int* launched, hipStream_t st, const float* dres32 = nullptr, float* dx32 = nullptr) {
   const int nch = cdiv(D, 256);
   dim3 b(LN_WAVES * 64);
   // one resident round: as many workgroups as the instantiation's occupancy holds (never more than the workspace rows)
@@ -716,6 +724,25 @@ static int ln_bwd_t(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap
                        (const TX*)x, ldx, xmap, mean, rstd, gamma, (const T*)dres, (T*)dx, lddx, part); \
     *launched = (int)g.x;                                                                          \
   }
+#define LN_BWD_G_(N, F)                                                                            \
+  {                                                                                                \
+    static int per_cu = 0;                                                                         \
+    if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_bwd_kernel<T, N, F, true, TX, true>, LN_WAVES * 64, 0) \
+                        != hipSuccess || per_cu <= 0)) per_cu = 1;                                 \
+    dim3 g(nblocks < per_cu * n_cu ? nblocks : per_cu * n_cu);                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, N, F, true, TX, true>), g, b, 0, st, rows, D, (const T*)dy, lddy, dymap, \
+                       (const TX*)x, ldx, xmap, mean, rstd, gamma, (const T*)nullptr, (T*)dx, lddx, part, dres32, dx32); \
+    *launched = (int)g.x;                                                                          \
+  }
+  if constexpr (sizeof(T) == 2 && sizeof(TX) == 4) {
+    if (dres32) {                                  // float32 gradient stream (vtx_layernorm_bwd_g32): D <= 1024 like the forward kernel
+#define LN_BWD_G(N) { if (D == N * 256) LN_BWD_G_(N, true) else LN_BWD_G_(N, false) }
+      if (nch == 1) LN_BWD_G(1) else if (nch == 2) LN_BWD_G(2) else if (nch == 3) LN_BWD_G(3) else LN_BWD_G(4)
+#undef LN_BWD_G
+      return check_launch("layernorm_bwd_g32");
+    }
+  }
+#undef LN_BWD_G_
 #define LN_BWD(N)                                                                                  \
   if (D == N * 256) { if (dres) LN_BWD_(N, true, true) else LN_BWD_(N, true, false) }              \
   else { if (dres) LN_BWD_(N, false, true) else LN_BWD_(N, false, false) }
@@ -802,5 +829,27 @@ extern "C" int vtx_layernorm_bwd(int dtype, int rows, int D, const void* dy, lon
     VTX_REQUIRE(false, VTX_EINVAL, "layernorm_bwd: bad dtype %d", dtype);
   if (rc) return rc;
   // part layout: [block][2][D] -> dgamma += sum_b part[b][0], dbeta += sum_b part[b][1] (one launch)
+  return launch_reduce_partials(part, launched, 2L * D, 2L * D, dgamma, 1, 1.0f, st, dbeta, D, 1);
+}
+
+// The float32 GRADIENT stream (bf16 kernels, exact residual stream): dx32 = dres32 + LayerNorm-backward(dy) on the mapped rows in
+// float32, dx = bf16(dx32).  x is the float32 stream vtx_layernorm_acc_fwd stored; dres32 / dx32 / dx share xmap and lddx.
+extern "C" int vtx_layernorm_bwd_g32(int rows, int D, const void* dy, long lddy, vtx_rowmap dymap, const float* x, long ldx,
+                                     vtx_rowmap xmap, const float* mean, const float* rstd, const float* gamma,
+                                     const float* dres32, float* dx32, void* dx, long lddx, float* dgamma, float* dbeta,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+  VTX_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 1024, VTX_EINVAL, "layernorm_bwd_g32: D=%d must be a multiple of 4 and <= 1024", D);
+  VTX_REQUIRE(dy && x && mean && rstd && gamma && dres32 && dx32 && dx && dgamma && dbeta && workspace, VTX_EINVAL,
+              "layernorm_bwd_g32: null pointer");
+  VTX_REQUIRE(ws_bytes >= vtx_layernorm_bwd_workspace(rows, D), VTX_EWS, "layernorm_bwd_g32: workspace too small");
+  VTX_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(dres32) && aligned16(dx32) && lddy % 4 == 0 && ldx % 4 == 0 &&
+                  lddx % 4 == 0, VTX_EALIGN, "layernorm_bwd_g32: 16-byte alignment required");
+  const int nb = ln_bwd_blocks(rows);
+  float* part = (float*)workspace;
+  hipStream_t st = as_stream(stream);
+  int launched = nb;
+  const int rc = ln_bwd_t<bf16raw, float>(rows, D, dy, lddy, dymap, x, ldx, xmap, mean, rstd, gamma, nullptr, dx, lddx, part, nb, &launched, st,
+                                          dres32, dx32);
+  if (rc) return rc;
   return launch_reduce_partials(part, launched, 2L * D, 2L * D, dgamma, 1, 1.0f, st, dbeta, D, 1);
 }

@@ -56,16 +56,19 @@ def set_stream(kind):
     layers, 3x at 24) or 'fp32' (the exact stream: sub-blocks hand on their contribution, the running sum lives in float32 and is
     advanced inside the next LayerNorm kernel -- what torch.autocast does in the reference; +0.7 GB of HBM traffic per sub-block at
     96 clips, +4 % step time).  Every attention type of TimeSformer / ViViT; the float32 precision mode is its own exact stream."""
-    if kind not in ('bf16', 'fp32'):
+    if kind not in ('bf16', 'fp32', 'fp32+grad'):
         raise ValueError(kind)
-    functions.set_exact_stream(kind == 'fp32')
+    functions.set_exact_stream(kind != 'bf16')
+    # 'fp32+grad': the stream's GRADIENT stays float32 through the backward as well (vtx_layernorm_bwd_g32): both directions of
+    # `x = x + f(norm(x))` as torch.autocast runs them; +6 bytes per element and sub-block on the LayerNorm backward
+    functions.set_exact_grad_stream(kind == 'fp32+grad')
 
 
 def get_stream():
-    return 'fp32' if functions.exact_stream() else 'bf16'
+    return ('fp32+grad' if functions.exact_grad_stream() else 'fp32') if functions.exact_stream() else 'bf16'
 
 
 import os as _os  # noqa: E402
 
-if _os.environ.get('VTX_STREAM', 'bf16') == 'fp32':      # initial value for entry points that keep the reference's flag list (model_pretrain.py)
-    set_stream('fp32')
+if _os.environ.get('VTX_STREAM', 'bf16') in ('fp32', 'fp32+grad'):      # initial value for entry points that keep the reference's flag list (model_pretrain.py)
+    set_stream(_os.environ['VTX_STREAM'])

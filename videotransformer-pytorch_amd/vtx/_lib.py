@@ -115,6 +115,7 @@ SIGNATURES = {
     'vtx_layernorm_bwd_workspace': (sz, [ci, ci]),
     'vtx_layernorm_bwd': (ci, [ci, ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, vp, vp, vp, vp, cl,
                                vp, vp, vp, sz, vp]),
+    'vtx_layernorm_bwd_g32': (ci, [ci, ci, vp, cl, RowMap, vp, cl, RowMap, vp, vp, vp, vp, vp, vp, cl, vp, vp, vp, sz, vp]),
     'vtx_gemm_nt_workspace': (sz, []),
     'vtx_gemm_nt': (ci, [C.POINTER(GemmDesc), vp]),
     'vtx_gemm_tn_workspace': (sz, [ci, ci, ci]),

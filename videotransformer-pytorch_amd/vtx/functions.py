@@ -216,6 +216,56 @@ def exact_stream():
     return _exact
 
 
+_exact_grad = False
+
+
+def set_exact_grad_stream(on):
+    """With the exact residual stream: keep the stream's GRADIENT in float32 too (vtx_layernorm_bwd_g32).  The backward of a
+    sub-block then reads the float32 gradient of its output next to the bf16 rounding autograd hands it, adds its LayerNorm
+    backward in float32 and hands both on: the running sum of the branch gradients is never rounded to bf16 -- as under
+    torch.autocast, where the stream and therefore its gradient are float32 and only the branches compute in bf16."""
+    global _exact_grad
+    _exact_grad = bool(on)
+
+
+def exact_grad_stream():
+    return _exact_grad
+
+
+def _grad_stream(dout, x_stream):
+    """The float32 stream gradient `dout` is the bf16 rounding of: the buffer the producing backward attached to it (valid
+    only while `dout` is that very tensor, unmodified: autograd's in-place accumulation of a second consumer's gradient bumps
+    the version counter, an out-of-place sum or a view is another object), else a float32 copy of `dout` -- the gradient
+    stream starts (or restarts) there.  None when the mode is off or the block did not run under the exact stream."""
+    if not _exact_grad or x_stream.dtype != torch.float32 or dout.dtype != torch.bfloat16:
+        return None
+    h = getattr(dout, '_vtx_g32', None)
+    if h is not None and h[1] == dout._version and h[0].shape == dout.shape and h[0].device == dout.device:
+        return h[0]
+    return ops.cast_to_f32(dout)
+
+
+def _hand_on(dx, dx32):
+    if dx32 is not None:
+        dx._vtx_g32 = (dx32, dx._version)
+    return dx
+
+
+def _ln_bwd_res(dxn, x_stream, xmap, rows, D, mean, rstd, ln_w, dout, dx, d_ln_w, d_ln_b, g32, dx32):
+    """dx = dout + LayerNorm-backward(dxn) on the mapped rows; with g32 / dx32 in float32 (dx its bf16 rounding)."""
+    if g32 is not None:
+        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, xmap, rows, D, mean, rstd, ln_w, None, dx, D, d_ln_w, d_ln_b, dres32=g32, dx32=dx32)
+    else:
+        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, xmap, rows, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+
+
+def _copy_rows_res(dout, dx, g32, dx32, rows, D, rowmap):
+    """Rows the block does not touch: their gradient passes through (both forms of it)."""
+    ops.row_scale_copy(dout, dx, rows, D, smap=rowmap, dmap=rowmap)
+    if g32 is not None:
+        ops.row_scale_copy(g32, dx32, rows, D, smap=rowmap, dmap=rowmap)
+
+
 _zero1 = {}
 
 
@@ -376,12 +426,15 @@ class TimeAttnFn(torch.autograd.Function):
         ops.gemm_nt(dqkv, wqT, dxn, M, D, 3 * D)
         # LayerNorm + residual
         dx = torch.empty_like(x)
+        g32 = _grad_stream(dout, x_stream)
+        dx32 = torch.empty_like(g32) if g32 is not None else None
         d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, tm, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        _ln_bwd_res(dxn, x_stream, tm, M, D, mean, rstd, ln_w, dout, dx, d_ln_w, d_ln_b, g32, dx32)
         if direct:
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
-        ops.row_scale_copy(dout, dx, B, D, smap=ops.clsmap(N), dmap=ops.clsmap(N))
+        _copy_rows_res(dout, dx, g32, dx32, B, D, ops.clsmap(N))
+        _hand_on(dx, dx32)
         return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, d_tfc_w, d_tfc_b, None, None, None, None, None, None, None)
 
 
@@ -469,11 +522,14 @@ class SpaceAttnFn(torch.autograd.Function):
         dxn = _empty((M1, D), x)
         ops.gemm_nt(dqkv, wqT, dxn, M1, D, 3 * D)
         dx = torch.empty_like(x)
+        g32 = _grad_stream(dout, x_stream)
+        dx32 = torch.empty_like(g32) if g32 is not None else None
         d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, IDENT, M1, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        _ln_bwd_res(dxn, x_stream, IDENT, M1, D, mean, rstd, ln_w, dout, dx, d_ln_w, d_ln_b, g32, dx32)
         if direct:
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
+        _hand_on(dx, dx32)
         return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None, None, None)
 
 
@@ -546,7 +602,10 @@ class SelfAttnFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         d_ln_w = torch.zeros(D, dtype=torch.float32, device=x.device)
         d_ln_b = torch.zeros(D, dtype=torch.float32, device=x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        g32 = _grad_stream(dout, x_stream)
+        dx32 = torch.empty_like(g32) if g32 is not None else None
+        _ln_bwd_res(dxn, x_stream, IDENT, M, D, mean, rstd, ln_w, dout, dx, d_ln_w, d_ln_b, g32, dx32)
+        _hand_on(dx, dx32)
         return (dx, d_ln_w, d_ln_b, d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, None, None, None, None, None, None)
 
 
@@ -700,6 +759,8 @@ class FFNFn(torch.autograd.Function):
         Mk = nk * rows_per
         x_stream, x = x, dout                          # (the saved stream may be float32: buffers take dout's dtype)
         dx = torch.empty_like(x)
+        g32 = _grad_stream(dout, x_stream)
+        dx32 = torch.empty_like(g32) if g32 is not None else None
         d_ln_w = d_ln_b = d_w1 = d_b1 = d_w2 = d_b2 = None
         if nk > 0:
             dz = _empty((Mk, D), x)
@@ -711,7 +772,7 @@ class FFNFn(torch.autograd.Function):
             dxn = _empty((Mk, D), x)
             ops.gemm_nt(dh, w1T, dxn, Mk, D, Hd)
             d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-            ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, kmap, Mk, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+            _ln_bwd_res(dxn, x_stream, kmap, Mk, D, mean, rstd, ln_w, dout, dx, d_ln_w, d_ln_b, g32, dx32)
             if direct:
                 _fire(p_ln_w, p_ln_b)
                 d_ln_w = d_ln_b = None
@@ -721,7 +782,8 @@ class FFNFn(torch.autograd.Function):
                     _fire(p)
             zeros = [None if _sink(p) is not None else torch.zeros_like(p) for p in (p_ln_w, p_ln_b, p_w1, p_b1, p_w2, p_b2)]
             d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2 = zeros
-        ops.row_scale_copy(dout, dx, nd * rows_per, D, smap=dmap, dmap=dmap)
+        _copy_rows_res(dout, dx, g32, dx32, nd * rows_per, D, dmap)
+        _hand_on(dx, dx32)
         return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None, None, None)
 
     @staticmethod
@@ -748,11 +810,14 @@ class FFNFn(torch.autograd.Function):
         dxn = _empty((M, D), x)
         ops.gemm_nt(dh, w1T, dxn, M, D, Hd)
         dx = torch.empty_like(x)
+        g32 = _grad_stream(dout, x_stream)
+        dx32 = torch.empty_like(g32) if g32 is not None else None
         d_ln_w, d_ln_b, direct = _ln_grad_buffers(p_ln_w, p_ln_b, D, x.device)
-        ops.layernorm_bwd(dxn, D, IDENT, x_stream, D, IDENT, M, D, mean, rstd, ln_w, dout, dx, D, d_ln_w, d_ln_b)
+        _ln_bwd_res(dxn, x_stream, IDENT, M, D, mean, rstd, ln_w, dout, dx, d_ln_w, d_ln_b, g32, dx32)
         if direct:
             _fire(p_ln_w, p_ln_b)
             d_ln_w = d_ln_b = None
+        _hand_on(dx, dx32)
         return (dx, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, None, None, None, None)
 
 

@@ -151,10 +151,20 @@ def layernorm_acc_fwd(xs, d, rows, D, lds, smap, xo, ldo, omap, gamma=None, beta
              float(eps), ptr(y), ldy, ymap, ptr(mean), ptr(rstd), stream())
 
 
-def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dres, dx, lddx, dgamma, dbeta):
+def layernorm_bwd(dy, lddy, dymap, x, ldx, xmap, rows, D, mean, rstd, gamma, dres, dx, lddx, dgamma, dbeta, dres32=None, dx32=None):
+    """dx = (dres or 0) + LN'(dy); with dres32 / dx32 (float32 gradient stream, bf16 kernels over the float32 stream x):
+    dx32 = dres32 + LN'(dy) in float32, dx = bf16(dx32) (vtx_layernorm_bwd_g32; ``dres`` is not read)."""
     need_cuda(dy, x, dx)
     ws_bytes = _lib.load().vtx_layernorm_bwd_workspace(rows, D)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    if dres32 is not None:
+        need_cuda(dres32, dx32)
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.float32 or dres32.dtype != torch.float32 or dx32.dtype != torch.float32:
+            raise TypeError('layernorm_bwd: the float32 gradient stream takes bf16 dy / dx and float32 x / dres32 / dx32')
+        with _timed('ln_bwd', nbytes=(2 + 4 + 4 + 4 + 2) * rows * D, key=f'g32 {rows}x{D}'):
+            call('vtx_layernorm_bwd_g32', rows, D, ptr(dy), lddy, dymap, ptr(x), ldx, xmap, ptr(mean), ptr(rstd), ptr(gamma), ptr(dres32),
+                 ptr(dx32), ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), ws_bytes, stream())
+        return
     # bf16 gradients with x stored as float32: the exact residual stream (vtx.set_stream('fp32'))
     mixed = dy.dtype == torch.bfloat16 and x.dtype == torch.float32
     with _timed('ln_bwd', nbytes=((3.0 if dres is not None else 2.0) * dy.element_size() + x.element_size()) * rows * D, key=f'{rows}x{D}'):
