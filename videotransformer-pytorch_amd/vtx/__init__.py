@@ -55,7 +55,10 @@ def set_stream(kind):
     form, whose rounding of the running sum grows with sqrt(depth): 2x the reference's own autocast deviation on outputs at 12
     layers, 3x at 24) or 'fp32' (the exact stream: sub-blocks hand on their contribution, the running sum lives in float32 and is
     advanced inside the next LayerNorm kernel -- what torch.autocast does in the reference; +0.7 GB of HBM traffic per sub-block at
-    96 clips, +4 % step time).  Every attention type of TimeSformer / ViViT; the float32 precision mode is its own exact stream."""
+    96 clips, +4 % step time) or 'fp32+grad' (the exact stream AND its gradient in float32 through the backward: the LayerNorm
+    backward of every sub-block adds its term to the float32 gradient of the stream and hands on the sum and its one bf16 rounding;
+    +7 % step time in all, worst parameter gradient at 12 layers 1.8e-2 -> 1.1e-2 off the fp32 reference).  Every attention type of
+    TimeSformer / ViViT; the float32 precision mode is its own exact stream."""
     if kind not in ('bf16', 'fp32', 'fp32+grad'):
         raise ValueError(kind)
     functions.set_exact_stream(kind != 'bf16')
