@@ -312,10 +312,12 @@ def other_configs(dev, model8, head8, budget_s=40.0):
             classifier(model8, head8), b, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=12, warmup=3)
     # the headline model and batch with the EXACT residual stream (vtx.set_stream('fp32'): the running sum of the residual stream in
     # float32 as under the reference's autocast) -- what the accuracy mode costs
-    vtx.set_stream('fp32')
+    # ('fp32+grad': the stream's gradient in float32 through the backward as well -- vtx_layernorm_bwd_g32)
     try:
-        run("TimeSformer-B divided_space_time, 8x3x224x224, bf16 with the exact float32 residual stream (vtx.set_stream('fp32')), fwd+CE+bwd+SGD, 96 clips per GPU",
-            classifier(model8, head8), 96, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=6, warmup=2)
+        for mode, what in (('fp32', 'the exact float32 residual stream'), ('fp32+grad', 'the exact float32 residual stream and its float32 gradient')):
+            vtx.set_stream(mode)
+            run(f"TimeSformer-B divided_space_time, 8x3x224x224, bf16 with {what} (vtx.set_stream('{mode}')), fwd+CE+bwd+SGD, 96 clips per GPU",
+                classifier(model8, head8), 96, 8, FLOPS_FWD_BWD_PER_CLIP[8], steps=6, warmup=2)
     finally:
         vtx.set_stream('bf16')
     run('TimeSformer-B divided_space_time, 16x3x224x224, bf16, fwd+CE+bwd+SGD (north_star second shape)',
