@@ -12,6 +12,8 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $R/bench.
 python $R/tools/rocpd_stats.py /tmp/prof_kt > $O/${TAG}_rocprofv3_kernel_stats_b96.csv
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_exact -- python $R/bench.py --stream fp32 --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_exact_under_rocprof.log 2>&1
 python $R/tools/rocpd_stats.py /tmp/prof_kt_exact > $O/${TAG}_rocprofv3_kernel_stats_exact_b96.csv
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_exact_grad -- python $R/bench.py --stream fp32+grad --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_exact_grad_under_rocprof.log 2>&1
+python $R/tools/rocpd_stats.py /tmp/prof_kt_exact_grad > $O/${TAG}_rocprofv3_kernel_stats_exact_grad_b96.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C -d /tmp/prof_$C -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-other-configs > /tmp/log_$C.txt 2>&1
   python $R/tools/pmc_dump.py /tmp/prof_$C > $O/${TAG}_pmc_${C}_b96.txt
@@ -22,6 +24,7 @@ cd $R
 timeout 900 python bench.py > $O/${TAG}_bench_default_b96.log 2>&1; tail -1 $O/${TAG}_bench_default_b96.log | cut -c1-300
 VTX_FORCE_DP=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown --no-other-configs > $O/${TAG}_bench_force_dp_b96.log 2>&1; tail -1 $O/${TAG}_bench_force_dp_b96.log | cut -c1-200
 timeout 300 python bench.py --stream fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_exact_stream_b96.log 2>&1; tail -1 $O/${TAG}_bench_exact_stream_b96.log | cut -c1-200
+timeout 300 python bench.py --stream fp32+grad --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_exact_grad_stream_b96.log 2>&1; tail -1 $O/${TAG}_bench_exact_grad_stream_b96.log | cut -c1-200
 timeout 300 python tools/hog_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_hog.txt; cat $O/${TAG}_hog.txt
 timeout 600 python tools/other_configs.py vivit tsf16 tsfl96_stored tsfl96_12 > $O/${TAG}_other_configs.txt 2>&1; cut -c1-250 $O/${TAG}_other_configs.txt | grep -v amdgpu.ids
 timeout 300 python tools/maskfeat_bench.py 32 3 > $O/${TAG}_maskfeat.txt 2>&1; tail -1 $O/${TAG}_maskfeat.txt | cut -c1-250
