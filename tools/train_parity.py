@@ -35,6 +35,9 @@ def main():
     from vtx import optim
     from oracle import synth, vt_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 8, 16))
+    for kv in [a.split('=', 1) for i, a in enumerate(sys.argv) if i and sys.argv[i - 1] == '--opt']:      # --opt attn_valu=1 (vtx.set_option)
+        vtx.set_option(kv[0], kv[1])
+        print(f'option {kv[0]} = {kv[1]}')
     full = opt('--full', 0)
     top = opt('--top', 0)
     which = opt('--model', 'timesformer')
@@ -118,9 +121,11 @@ def main():
             if top:
                 tot2 = (flat(p) - fr).norm().item() ** 2
                 per = sorted(((((p[k].double() - ref_p[k].double()).norm().item() ** 2) / tot2, k) for k in ref_p), reverse=True)[:top]
-                print('      largest shares of the squared drift: ' + '; '.join(
-                    f'{k} {sh:.2f} (rel {(p[k].double() - ref_p[k].double()).norm().item() / max((ref_p[k].double() - sd0[k].double()).norm().item(), 1e-30):.2e} of its own travel)'
-                    for sh, k in per))
+                own = lambda q, k: (q[k].double() - ref_p[k].double()).norm().item() / max((ref_p[k].double() - sd0[k].double()).norm().item(), 1e-30)      # noqa: E731
+                amp = arms['oracle + autocast'][0]
+                print('      largest shares of the squared drift (tensor: share, error relative to its own travel, the same for the reference AMP arm):')
+                for sh, k in per:
+                    print(f'         {k}: {sh:.3f}  {own(p, k):.3e}  (AMP {own(amp, k):.3e}: x {own(p, k) / max(own(amp, k), 1e-30):.2f})')
             t = tot.setdefault(name, [0.0, 0.0, 0.0])
             t[0] += dstep / nseeds; t[1] += dy / nseeds; t[2] += dl / nseeds
     print('means over the seeds:')

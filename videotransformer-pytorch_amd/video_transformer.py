@@ -54,9 +54,14 @@ class _VideoTransformerBase(nn.Module):
         proj = self.patch_embed.projection
         dev = x.device
         pos = _embed(self.pos_embed, dev) if pos_embed is None or pos_embed is self.pos_embed else pos_embed
-        return F_.TokensFn.apply(x, proj.weight, proj.bias, self.cls_token, pos,
-                                 None if time_embed is None else _embed(time_embed, dev),
-                                 vtx.compute_dtype(), layout)
+        dtype = vtx.compute_dtype()
+        exact = F_.exact_stream() and dtype == torch.bfloat16
+        out = F_.TokensFn.apply(x, proj.weight, proj.bias, self.cls_token, pos,
+                                None if time_embed is None else _embed(time_embed, dev), dtype, layout, exact)
+        if exact:                                    # the stream starts in float32 (transformer._stream_of reads the attribute)
+            out, xs0 = out
+            out._vtx_xs = xs0
+        return out
 
     def _readout(self, x):
         # under vtx.set_stream('fp32') x is the last sub-block's contribution and carries the float32 stream (transformer._stream_of)

@@ -830,7 +830,11 @@ class TokensFn(torch.autograd.Function):
     layout 'tp': [(B T'), 1+P, D]                 (space_only, ViViT fact_encoder)"""
 
     @staticmethod
-    def forward(ctx, clip, conv_w, conv_b, cls_token, pos_embed, time_embed, dtype, layout):
+    def forward(ctx, clip, conv_w, conv_b, cls_token, pos_embed, time_embed, dtype, layout, exact=False):
+        # exact (the exact residual stream, bf16 kernels): the stream STARTS in float32 as it does in the reference under autocast --
+        # the patch projection is a bf16 tensor (bf16(acc + bias): the autocast Conv's output), the cat with the float32 cls token
+        # and the `+ pos_embed`, `+ time_embed` adds promote to float32 (video_transformer.py:200-239).  Returns (d0, xs0): d0 the
+        # bf16 projection rows (cls rows 0), xs0 the float32 rest (pos + time; cls rows cls_token + pos[0]); xs0 + d0 is the stream.
         ops.need_cuda(clip, conv_w)
         B, T, Cc, H, W = ops.clip_dims(clip)
         D = conv_w.shape[0]
@@ -848,31 +852,41 @@ class TokensFn(torch.autograd.Function):
         if T % ts:
             raise ValueError(f'{T} frames are not a multiple of the tubelet size {ts}')
         wc, _ = weights(conv_w, dtype, False)
+        exact = bool(exact) and dtype == torch.bfloat16
+        tdt = torch.float32 if exact else dtype            # the embedding table: float32 and without the conv bias under the exact stream
         if layout == 'pt':
             rows = ops.patch_rows(clip, dtype, ps, ts, frame_major=False)        # [(b p t), K]
             N = P * Tq
-            E, cls_row = ops.embed_table(dtype, P, Tq, D, conv_b, pos_embed.reshape(-1, D),
+            E, cls_row = ops.embed_table(tdt, P, Tq, D, None if exact else conv_b, pos_embed.reshape(-1, D),
                                          None if time_embed is None else time_embed.reshape(-1, D),
                                          cls_token.reshape(-1))
-            x = torch.empty(B, 1 + N, D, dtype=dtype, device=clip.device)
-            ops.gemm_nt(rows, wc, x, B * N, D, K, cmap=ops.tokmap(N), R=E, r_period=N)
             nseq, per = B, N
         else:
             rows = ops.patch_rows(clip, dtype, ps, ts, frame_major=True)         # [(b t p), K]
-            E, cls_row = ops.embed_table(dtype, P, 1, D, conv_b, pos_embed.reshape(-1, D), None,
+            N = P
+            E, cls_row = ops.embed_table(tdt, P, 1, D, None if exact else conv_b, pos_embed.reshape(-1, D), None,
                                          cls_token.reshape(-1))
-            x = torch.empty(B * Tq, 1 + P, D, dtype=dtype, device=clip.device)
-            ops.gemm_nt(rows, wc, x, B * Tq * P, D, K, cmap=ops.tokmap(P), R=E, r_period=P)
             nseq, per = B * Tq, P
-        # cls rows: every sequence's row 0 = cls_token + pos_embed[0]
-        ops.row_scale_copy(cls_row, x, nseq, D, smap=ops.rowmap(1, -1, 0), dmap=ops.clsmap(per))
+        x = torch.empty(nseq, 1 + N, D, dtype=dtype, device=clip.device)
         ctx.save_for_backward(rows)
         ctx.cfg = (B, Tq, P, D, K, layout, conv_w.shape, pos_embed.shape,
                    None if time_embed is None else time_embed.shape, cls_token.shape)
+        if exact:
+            ops.gemm_nt(rows, wc, x, nseq * N, D, K, cmap=ops.tokmap(N), bias=conv_b)
+            ops.row_scale_copy(torch.zeros(D, dtype=dtype, device=clip.device), x, nseq, D, smap=ops.rowmap(1, -1, 0), dmap=ops.clsmap(per))
+            xs0 = torch.empty(nseq, 1 + N, D, dtype=torch.float32, device=clip.device)
+            xs0[:, 1:].copy_(E.view(1, N, D).expand(nseq, N, D))
+            xs0[:, 0].copy_(cls_row.view(1, D).expand(nseq, D))
+            ctx.mark_non_differentiable(xs0)
+            ctx.set_materialize_grads(False)
+            return x, xs0
+        ops.gemm_nt(rows, wc, x, nseq * N, D, K, cmap=ops.tokmap(N), R=E, r_period=N)
+        # cls rows: every sequence's row 0 = cls_token + pos_embed[0]
+        ops.row_scale_copy(cls_row, x, nseq, D, smap=ops.rowmap(1, -1, 0), dmap=ops.clsmap(per))
         return x
 
     @staticmethod
-    def backward(ctx, dx):
+    def backward(ctx, dx, _dxs=None):
         (rows,) = ctx.saved_tensors
         B, Tq, P, D, K, layout, w_shape, pos_shape, time_shape, cls_shape = ctx.cfg
         dx = _chk(dx)
@@ -894,7 +908,7 @@ class TokensFn(torch.autograd.Function):
                 d_time = ops.reduce_rows(dE, Tq, P, D, D, 0, Tq, 1).reshape(time_shape)
         else:
             d_pos[1:].copy_(dE)
-        return (None, d_w, d_b, d_cls.reshape(cls_shape), d_pos.reshape(pos_shape), d_time, None, None)
+        return (None, d_w, d_b, d_cls.reshape(cls_shape), d_pos.reshape(pos_shape), d_time, None, None, None)
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -1061,7 +1075,16 @@ class FactGlueFn(torch.autograd.Function):
         dh = _chk(dh)
         need_e = ctx.needs_input_grad[1]
         de = torch.empty(1 + T, D, dtype=torch.float32, device=dh.device) if need_e else None
-        dx = ops.fact_glue_bwd(dh, b, T, P, D, d_time_embed=de)
+        if _exact_grad and dh.dtype == torch.bfloat16:
+            # 'fp32+grad': a frame token's gradient / P goes to ALL P patch rows of the frame -- rounded to bf16 here, the same rounding
+            # error would sit on 196 rows at once and survive every weight-gradient sum over them.  The float32 gradient of the
+            # temporal stream in, the float32 gradient of the spatial stream out (its bf16 rounding is what the GEMMs read).
+            h = getattr(dh, '_vtx_g32', None)
+            g32 = h[0] if (h is not None and h[1] == dh._version and h[0].shape == dh.shape) else ops.cast_to_f32(dh)
+            dx32 = ops.fact_glue_bwd(g32, b, T, P, D, d_time_embed=de)
+            dx = _hand_on(ops.cast_from_f32(dx32, dh.dtype), dx32)
+        else:
+            dx = ops.fact_glue_bwd(dh, b, T, P, D, d_time_embed=de)
         return dx, (de.reshape(e_shape) if need_e else None), None
 
 
