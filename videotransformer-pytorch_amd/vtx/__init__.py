@@ -57,7 +57,7 @@ def set_stream(kind):
     advanced inside the next LayerNorm kernel -- what torch.autocast does in the reference; +0.7 GB of HBM traffic per sub-block at
     96 clips, +4 % step time) or 'fp32+grad' (the exact stream AND its gradient in float32 through the backward: the LayerNorm
     backward of every sub-block adds its term to the float32 gradient of the stream and hands on the sum and its one bf16 rounding;
-    +7 % step time in all, worst parameter gradient at 12 layers 1.8e-2 -> 1.1e-2 off the fp32 reference).  Every attention type of
+    +7 % step time in all; parameter gradients at 12 layers: worst 1.4e-2 -> 1.2e-2, median 8.5e-3 -> 7.2e-3 off the fp32 reference).  Every attention type of
     TimeSformer / ViViT; the float32 precision mode is its own exact stream."""
     if kind not in ('bf16', 'fp32', 'fp32+grad'):
         raise ValueError(kind)
