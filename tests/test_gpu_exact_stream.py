@@ -254,11 +254,14 @@ def test_timesformer_l_t96_full_depth_exact_stream():
     assert e <= 2.0 * ref_ac, f'exact stream {e:.3e} > 2 x the reference autocast deviation {ref_ac:.3e}'
 
 
-def test_bench_stack_exact_stream_with_partial_ffn_drop():
+@pytest.mark.parametrize('mode', ['fp32', 'fp32+grad'])
+def test_bench_stack_exact_stream_with_partial_ffn_drop(mode):
     """The bench stack (direct gradients into buckets, DropPath compaction with some clips of a layer dropped, merged projection)
     under the exact stream against the oracle at 8 clips: the dropped clips' stream rows move on through the accumulate-only
-    kernel, their contribution rows are zero."""
+    kernel, their contribution rows are zero ('fp32+grad': their float32 gradient rows pass through the block as they came)."""
+    import vtx
     import video_transformer as V
+    vtx.set_stream(mode)
     from vtx import dp
     from test_gpu_models import _ffn_drop_pattern
     B, T, L = 8, 16, 4
@@ -284,14 +287,14 @@ def test_bench_stack_exact_stream_with_partial_ffn_drop():
     torch.manual_seed(seed)
     yo = O.timesformer_forward(ps, x, T, heads=2, layers=L, training=True)
     (yo * w).sum().backward()
-    check('bench stack bf16 exact stream out', y.detach().cpu(), yo.detach(), TOL_BF16)
+    check(f'bench stack bf16 exact stream {mode} out', y.detach().cpu(), yo.detach(), TOL_BF16)
     worst = 0.0
     for k, gk in grads.items():
         ref = ps[k].grad
         e = (gk.double() - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-30)
         worst = max(worst, e)
         assert e <= TOL_BF16_GRAD, f'{k}: {e:.3e}'
-    report(f'bench stack bf16 exact stream: worst parameter gradient l2-rel {worst:.3e}')
+    report(f'bench stack bf16 exact stream {mode}: worst parameter gradient l2-rel {worst:.3e}')
 
 
 # ---- 'fp32+grad': the stream's gradient in float32 too ---------------------------------------------------------------------
